@@ -1,0 +1,152 @@
+/*
+ * lmh.h -- C ABI of the MI355X-native batched NAO whole-body controller
+ *          (LIPM preview MPC -> whole-body QP -> rigid-body terms -> torques).
+ *
+ * This is the drop-in boundary for the per-tick hot path of Ema158/linearMpcHumanoid.
+ * The reference has no FFI/plugin layer: its boundary is the C++ call surface used by
+ * apps/offline/main.cpp.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root).  The C++ classes with the reference's
+ * own names (Robot, Controller, Mpc3dLip, ZMP, ...) in
+ * linearmpchumanoid_amd/csrc/shim/linearMpcHumanoid/ are thin wrappers over this ABI.
+ *
+ * All compute runs in hand-written HIP kernels (gfx950).  There is NO CPU fallback:
+ * every call fails with LMH_ERR_NO_DEVICE if no HIP device is usable.
+ *
+ * Layouts (fp64, instance-major, contiguous):
+ *   state  [B][LMH_STATE_STRIDE]  : q(30) | v(30) | v_prev(30) | t | pad(5)
+ *       q = [p_base(3) world, rpy(3), qJ(24)], v = [v_lin(3), omega(3), qdJ(24)]
+ *       (include/linearMpcHumanoid/controller/controller.hpp:20-31).
+ *       v_prev is Robot::v_ as the previous Controller::standStep left it: the reference
+ *       evaluates C, Cg and Jdot*qdot BEFORE it stores the new velocity
+ *       (src/controller.cpp:56 vs :59), so those terms see the previous call's velocity.
+ *   out    [B][LMH_OUT_STRIDE]    : tau(24) | f(12: n_R f_R n_L f_L) | qdd(30) | pad(6)
+ *       (WBCOutput, controller.hpp:43-48)
+ *   status [B][LMH_STATUS_STRIDE] int32 : k | qp_iterations | flags | active_mask
+ *       k = int(t/dt) of the last evaluation (src/mpcLinearPendulum.cpp:92), bit-exact.
+ */
+#ifndef LMH_H
+#define LMH_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMH_NQ 30
+#define LMH_NJ 24
+#define LMH_NFRAMES 28
+#define LMH_STATE_STRIDE 96
+#define LMH_OUT_STRIDE 72
+#define LMH_STATUS_STRIDE 4
+#define LMH_LINK_STRIDE 13        /* mass | com(3) | inertia(9 row-major), linkInertia.hpp:4-9 */
+#define LMH_MAX_HORIZON 64
+#define LMH_DEBUG_STRIDE 4096
+
+/* status flags */
+#define LMH_FLAG_QP_MAXITER 1     /* active-set iteration cap hit (reference: "QP failed", controller.cpp:472-476) */
+#define LMH_FLAG_NONFINITE 2      /* NaN/Inf in the solution (reference aborts, controller.cpp:448-466) */
+#define LMH_FLAG_ZMP_RANGE 4      /* preview window [k, k+N] left the reference arrays */
+#define LMH_FLAG_NOT_SPD 8        /* a Cholesky pivot was not positive */
+
+/* support phase per preview sample (build-defined extension; reference: Task.hpp:9-13 SupportFoot) */
+#define LMH_PHASE_DOUBLE 0
+#define LMH_PHASE_RIGHT 1         /* right foot in support, left foot carries no force */
+#define LMH_PHASE_LEFT 2
+#define LMH_PHASE_FLIGHT 3
+
+enum {
+    LMH_OK = 0,
+    LMH_ERR_NO_DEVICE = -1,
+    LMH_ERR_BAD_ARG = -2,
+    LMH_ERR_HIP = -3,
+    LMH_ERR_NOT_READY = -4
+};
+
+/* Literals of the reference, gathered in one record (the reference has no config layer):
+ * include/linearMpcHumanoid/controller/controller.hpp:80-124, mpcLinearPendulum.hpp:43-49,
+ * src/controller.cpp:117, apps/offline/main.cpp:13-14,38-39. */
+typedef struct lmh_config {
+    double dt;             /* control step == MPC sample time (mpcLinearPendulum.cpp:43,92) */
+    double time_horizon;   /* N = (int)(time_horizon / dt)                                   */
+    double z_com;          /* LIPM height: Mpc3dLip ctor argument (main.cpp:39)              */
+    double gravity, alpha, beta;
+    double mu;
+    double kp_joints, kd_joints, kp_mom, kd_mom, kp_feet, kd_feet;
+    double w_com_lin, w_com_ang, w_base_pos, w_base_ang, w_joints, w_force, w_foot;
+    double eps_coeff;
+    int32_t warm_start;    /* 1: start the active set from the previous evaluation's (same minimiser) */
+    int32_t max_qp_iters;
+} lmh_config;
+
+typedef struct lmh_handle lmh_handle;
+
+/* fills the reference literals; dt = 0.01, time_horizon = 0.5, z_com = 0.26 */
+void lmh_config_default(lmh_config *cfg);
+const char *lmh_last_error(void);
+int lmh_device_count(void);
+
+/* replaces: Robot::Robot + Mpc3dLip::Mpc3dLip + Controller::Controller
+ * (src/Robot.cpp:5-43, src/mpcLinearPendulum.cpp:10-76, src/controller.cpp:5-46) for
+ * n_instances robots on HIP device `device`.  Loads the nominal NAO model and a constant
+ * (stance) reference set covering `default_ref_samples` samples. */
+int lmh_create(const lmh_config *cfg, int n_instances, int device, lmh_handle **out);
+int lmh_destroy(lmh_handle *h);
+int lmh_num_instances(const lmh_handle *h);
+int lmh_horizon(const lmh_handle *h);
+
+/* replaces: createNaoParameters (src/robotParameters.cpp:8-229) + the joint-frame
+ * re-expression of Robot::Robot (src/Robot.cpp:14-22).  raw_links: HOST pointer,
+ * [n_models][28][13] in the Aldebaran (world-aligned at q=0) convention; n_models is 1
+ * (shared) or n_instances (domain randomisation).  NULL restores the nominal table. */
+int lmh_set_model(lmh_handle *h, const double *raw_links, int n_models);
+/* total mass per model, HOST out [n_models] (Robot::getMass) */
+int lmh_get_mass(lmh_handle *h, double *mass);
+/* nominal raw table (HOST out [28][13]) */
+void lmh_nominal_links(double *raw_links);
+
+/* replaces: ZMP::getZmpXRef/getZmpYRef arrays copied into Controller (src/zmpGeneration.cpp:39-60,
+ * src/controller.cpp:14) + the support-phase extension.  HOST pointers, n_samples each;
+ * phase may be NULL (all double support). */
+int lmh_set_refs(lmh_handle *h, const double *zmp_x, const double *zmp_y, const uint8_t *phase, int n_samples);
+/* replaces: ZMP::stanceZMP (src/zmpGeneration.cpp:39-60); support_foot: 0 Right,1 Left,2 Double */
+int lmh_set_refs_stance(lmh_handle *h, double simulation_time, int support_foot);
+/* replaces: footCoeffTrajectory output copied into Controller (src/footRefTrajectory.cpp:4-47,
+ * src/controller.cpp:15-16).  coeff: HOST [3][8] ascending powers, n: [3] counts. */
+int lmh_set_foot_coeffs(lmh_handle *h, const double *r_coeff, const int32_t *r_n, const double *l_coeff, const int32_t *l_n);
+/* per-instance LIPM height (domain randomisation): HOST [n_instances]; rebuilds the gain rows */
+int lmh_set_zcom(lmh_handle *h, const double *z_com, int n);
+/* MPC gain row K (HOST out [N+1]) with u0 = -K (Px x_k - zmp[k:k+N+1]); instance 0 */
+int lmh_get_mpc_gain(lmh_handle *h, double *K);
+
+/* replaces: Controller::standStep + Controller::WBC (src/controller.cpp:48-154) for all
+ * instances.  DEVICE pointers; d_state is read AND updated (v_prev <- v, as Robot::v_ is);
+ * stream is a hipStream_t (NULL = default stream).  Asynchronous. */
+int lmh_eval(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, void *stream);
+/* same, additionally dumping intermediate terms for unit parity (DEVICE [B][LMH_DEBUG_STRIDE]) */
+int lmh_eval_debug(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, double *d_debug, void *stream);
+
+/* replaces: the closed loop of apps/offline/main.cpp:66-122 (rk4Step, rk4.hpp:5-18, of
+ * dynamics(); Clock::step, Clock.hpp:11) for n_ticks ticks, state resident on chip.
+ * d_out receives the k4-stage evaluation of the last tick; d_log (optional, DEVICE
+ * [n_ticks][B][36]) receives tau|f of the k4 stage of every tick.  Asynchronous. */
+int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, double *d_log,
+                int n_ticks, void *stream);
+
+/* replaces: Kinematics::desiredOperationalState + Kinematics::compute
+ * (src/invKinematics.cpp:11-52): Newton IK to feet (0,-/+0.05,0), com target, per instance.
+ * DEVICE d_q [B][30] in/out (start posture in, solution out); com_target HOST [3]. */
+int lmh_ik(lmh_handle *h, double *d_q, const double *com_target, const double *rf6, const double *lf6,
+           int32_t *d_iters, void *stream);
+
+/* host-buffer convenience used by the C++ shim (B instances, staged through internal
+ * device buffers, synchronous): q/dq [B][30], t, outputs tau[B][24], f[B][12], qdd[B][30] */
+int lmh_eval_host(lmh_handle *h, const double *q, const double *dq, double t,
+                  double *tau, double *f, double *qdd, int32_t *status);
+/* overwrite the staged Robot::v_ (v_prev) used by the next lmh_eval_host call: HOST [B][30] */
+int lmh_set_prev_velocity_host(lmh_handle *h, const double *v);
+int lmh_synchronize(lmh_handle *h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

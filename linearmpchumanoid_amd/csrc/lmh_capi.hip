@@ -1,0 +1,408 @@
+// lmh_capi.hip -- host side of the C ABI in include/lmh.h: owns the device-resident tables
+// (model, MPC gain rows, ZMP / phase references, friction generators), launches the gfx950
+// kernels in lmh_kernels.hip.  No CPU compute path exists: without a HIP device every entry
+// point fails with LMH_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/lmh.h"
+#include "lmh_device.h"
+#include "lmh_nao_model.h"
+
+extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s);
+extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
+extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, hipStream_t s);
+extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const double *target, int32_t *iters, hipStream_t s);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(LMH_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct lmh_handle {
+    lmh_config cfg;
+    int B = 0, device = 0, N = 0, n_models = 0, n_gain = 0, n_samples = 0;
+    double *d_model = nullptr, *d_mpc = nullptr, *d_zx = nullptr, *d_zy = nullptr, *d_gcol = nullptr, *d_raw = nullptr;
+    uint8_t *d_phase = nullptr;
+    // staging for the host-buffer convenience calls
+    double *d_state = nullptr, *d_out = nullptr, *d_tgt = nullptr;
+    int32_t *d_status = nullptr;
+    std::vector<double> h_state, h_out, h_gain;
+    std::vector<int32_t> h_status;
+    LmhDevParams P;
+};
+
+extern "C" const char *lmh_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lmh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void lmh_config_default(lmh_config *c)
+{
+    std::memset(c, 0, sizeof(*c));
+    c->dt = 0.01; c->time_horizon = 0.5; c->z_com = 0.26;          // apps/offline/main.cpp:13-14,31,38
+    c->gravity = 9.81; c->alpha = 1e-3; c->beta = 1.0;              // mpcLinearPendulum.hpp:46-48
+    c->mu = 0.7;                                                    // controller.hpp:81
+    c->kp_joints = 300; c->kd_joints = 34;                          // controller.hpp:102-103
+    c->kp_mom = 10; c->kd_mom = 6.32;                               // :106-107
+    c->kp_feet = 500; c->kd_feet = 44;                              // :110-111
+    c->w_com_lin = 4000; c->w_com_ang = 0; c->w_base_pos = 10; c->w_base_ang = 10;   // :118-121
+    c->w_joints = 1; c->w_force = 1; c->w_foot = 100000;            // :122-124
+    c->eps_coeff = 1e-8;                                            // controller.cpp:117
+    c->warm_start = 1; c->max_qp_iters = 64;
+}
+
+extern "C" void lmh_nominal_links(double *raw) { std::memcpy(raw, kLmhNaoLinks, sizeof(kLmhNaoLinks)); }
+
+// ---- Mpc3dLip::initialize (src/mpcLinearPendulum.cpp:41-68) + the algebraic gain row:
+// u = -H^-1 g, g = beta Pu'(Px x - z), H = alpha I + beta Pu'Pu  =>  u0 = -K (Px x - z),
+// K = beta e0' H^-1 Pu'.  Record layout: K | Px[:,0] | Px[:,1] | zcom | pad(3).
+static int build_gain_row(const lmh_config &c, double zcom, int N, double *rec)
+{
+    const int n = N + 1;
+    const double dt = c.dt;
+    std::vector<double> Pu((size_t)n * n, 0.0), H((size_t)n * n), h0(n, 0.0);
+    double A[4] = {1, dt, 0, 1}, B[2] = {(dt * dt) / 2, dt}, Ap[4] = {1, 0, 0, 1};
+    const double D = -zcom / c.gravity;
+    double *K = rec, *px0 = rec + n, *px1 = rec + 2 * n;
+    px0[0] = 1; px1[0] = 0;
+    Pu[0] = D;
+    for (int i = 1; i <= N; i++) {
+        double t[4] = {Ap[0] * A[0] + Ap[1] * A[2], Ap[0] * A[1] + Ap[1] * A[3], Ap[2] * A[0] + Ap[3] * A[2], Ap[2] * A[1] + Ap[3] * A[3]};
+        std::memcpy(Ap, t, sizeof(t));
+        px0[i] = Ap[0]; px1[i] = Ap[1];                             // C = [1 0]
+        Pu[(size_t)i * n + i - 1] = B[0];
+        Pu[(size_t)i * n + i] = D;
+        double Aj[4] = {1, 0, 0, 1};
+        for (int j = 1; j <= N - i; j++) {
+            double u[4] = {Aj[0] * A[0] + Aj[1] * A[2], Aj[0] * A[1] + Aj[1] * A[3], Aj[2] * A[0] + Aj[3] * A[2], Aj[2] * A[1] + Aj[3] * A[3]};
+            std::memcpy(Aj, u, sizeof(u));
+            Pu[(size_t)(i + j) * n + i - 1] = Aj[0] * B[0] + Aj[1] * B[1];
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int l = 0; l < n; l++) s += Pu[(size_t)l * n + i] * Pu[(size_t)l * n + j];
+            H[(size_t)i * n + j] = ((i == j) ? c.alpha : 0.0) + c.beta * s;
+        }
+    for (int j = 0; j < n; j++) {                                   // Cholesky (lower)
+        double d = H[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= H[(size_t)j * n + k] * H[(size_t)j * n + k];
+        if (!(d > 0)) return 1;
+        d = std::sqrt(d);
+        H[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = H[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) s -= H[(size_t)i * n + k] * H[(size_t)j * n + k];
+            H[(size_t)i * n + j] = s / d;
+        }
+    }
+    std::vector<double> y(n, 0.0);
+    for (int i = 0; i < n; i++) {                                   // H h0 = e0
+        double s = (i == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < i; k++) s -= H[(size_t)i * n + k] * y[k];
+        y[i] = s / H[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < n; k++) s -= H[(size_t)k * n + i] * h0[k];
+        h0[i] = s / H[(size_t)i * n + i];
+    }
+    for (int i = 0; i < n; i++) {
+        double s = 0;
+        for (int j = 0; j < n; j++) s += Pu[(size_t)i * n + j] * h0[j];
+        K[i] = c.beta * s;
+    }
+    rec[3 * n] = zcom; rec[3 * n + 1] = rec[3 * n + 2] = rec[3 * n + 3] = 0.0;
+    return 0;
+}
+
+// friction-cone generators: column j = 16 foot + 4 vertex + edge  ->  [p_v x ray_e ; ray_e]
+// (src/controller.cpp:33-36,185-270, vertices src/Robot.cpp:38-42; same for both feet)
+static void build_gcol(double mu, double *g /*[32][6]*/)
+{
+    const double ray[4][3] = {{mu, 0, 1}, {0, mu, 1}, {-mu, 0, 1}, {0, -mu, 1}};
+    const double vtx[4][3] = {{0.1, 0.025, 0}, {0.1, -0.025, 0}, {-0.05, 0.025, 0}, {-0.05, -0.025, 0}};
+    for (int ft = 0; ft < 2; ft++)
+        for (int v = 0; v < 4; v++)
+            for (int e = 0; e < 4; e++) {
+                double *o = g + 6 * (16 * ft + 4 * v + e);
+                const double *p = vtx[v], *r = ray[e];
+                // crossMatrix(p) * ray, term by term as the dense product does
+                o[0] = 0 * r[0] + (-p[2]) * r[1] + p[1] * r[2];
+                o[1] = p[2] * r[0] + 0 * r[1] + (-p[0]) * r[2];
+                o[2] = (-p[1]) * r[0] + p[0] * r[1] + 0 * r[2];
+                o[3] = r[0]; o[4] = r[1]; o[5] = r[2];
+            }
+}
+
+static void fill_params(lmh_handle *h)
+{
+    LmhDevParams &P = h->P;
+    const lmh_config &c = h->cfg;
+    P.model = h->d_model; P.mpc = h->d_mpc; P.zmpx = h->d_zx; P.zmpy = h->d_zy; P.phase = h->d_phase; P.gcol = h->d_gcol;
+    P.model_stride = (h->n_models > 1) ? LMH_MODEL_STRIDE : 0;
+    P.mpc_stride = 3 * (h->N + 1) + 4;
+    P.mpc_stride_inst = (h->n_gain > 1) ? P.mpc_stride : 0;
+    P.n_samples = h->n_samples; P.horizon = h->N; P.n_instances = h->B;
+    P.warm_start = c.warm_start; P.max_qp_iters = c.max_qp_iters;
+    P.dt = c.dt;
+    P.kp_joints = c.kp_joints; P.kd_joints = c.kd_joints; P.kp_mom = c.kp_mom; P.kd_mom = c.kd_mom;
+    P.kp_feet = c.kp_feet; P.kd_feet = c.kd_feet;
+    P.w_com_lin = c.w_com_lin; P.w_com_ang = c.w_com_ang; P.w_base_pos = c.w_base_pos; P.w_base_ang = c.w_base_ang;
+    P.w_joints = c.w_joints; P.w_force = c.w_force; P.w_foot = c.w_foot; P.eps_coeff = c.eps_coeff;
+    P.a00 = 1; P.a01 = c.dt; P.a10 = 0; P.a11 = 1; P.b0 = (c.dt * c.dt) / 2; P.b1 = c.dt;
+}
+
+static int upload_gain(lmh_handle *h, const double *zcom, int n)
+{
+    const int stride = 3 * (h->N + 1) + 4;
+    h->h_gain.assign((size_t)n * stride, 0.0);
+    for (int i = 0; i < n; i++)
+        if (build_gain_row(h->cfg, zcom[i], h->N, h->h_gain.data() + (size_t)i * stride))
+            return fail(LMH_ERR_BAD_ARG, "MPC Hessian not positive definite");
+    if (h->d_mpc) { HIPCHK(hipFree(h->d_mpc)); h->d_mpc = nullptr; }
+    HIPCHK(hipMalloc(&h->d_mpc, sizeof(double) * h->h_gain.size()));
+    HIPCHK(hipMemcpy(h->d_mpc, h->h_gain.data(), sizeof(double) * h->h_gain.size(), hipMemcpyHostToDevice));
+    h->n_gain = n;
+    fill_params(h);
+    return LMH_OK;
+}
+
+extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lmh_handle **out)
+{
+    if (!cfg || !out || n_instances < 1) return fail(LMH_ERR_BAD_ARG, "lmh_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LMH_ERR_NO_DEVICE, "no HIP device: the controller has no CPU path");
+    if (device < 0 || device >= ndev) return fail(LMH_ERR_BAD_ARG, "lmh_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    lmh_handle *h = new lmh_handle();
+    h->cfg = *cfg; h->B = n_instances; h->device = device;
+    h->N = (int)(cfg->time_horizon / cfg->dt);                      // mpcLinearPendulum.cpp:43
+    if (h->N < 1 || h->N > LMH_MAX_HORIZON) { delete h; return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/dt must be in [1, 64]"); }
+    std::memset(&h->P, 0, sizeof(h->P));
+    double g[32 * 6];
+    build_gcol(cfg->mu, g);
+    HIPCHK(hipMalloc(&h->d_gcol, sizeof(g)));
+    HIPCHK(hipMemcpy(h->d_gcol, g, sizeof(g), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_state, sizeof(double) * LMH_STATE_STRIDE * (size_t)n_instances));
+    HIPCHK(hipMalloc(&h->d_out, sizeof(double) * LMH_OUT_STRIDE * (size_t)n_instances));
+    HIPCHK(hipMalloc(&h->d_status, sizeof(int32_t) * LMH_STATUS_STRIDE * (size_t)n_instances));
+    HIPCHK(hipMalloc(&h->d_tgt, sizeof(double) * 16));
+    HIPCHK(hipMemset(h->d_state, 0, sizeof(double) * LMH_STATE_STRIDE * (size_t)n_instances));
+    HIPCHK(hipMemset(h->d_status, 0, sizeof(int32_t) * LMH_STATUS_STRIDE * (size_t)n_instances));
+    h->h_state.assign((size_t)LMH_STATE_STRIDE * n_instances, 0.0);
+    h->h_out.assign((size_t)LMH_OUT_STRIDE * n_instances, 0.0);
+    h->h_status.assign((size_t)LMH_STATUS_STRIDE * n_instances, 0);
+    *out = h;
+    int rc = lmh_set_model(h, nullptr, 1);
+    if (rc == LMH_OK) rc = upload_gain(h, &cfg->z_com, 1);
+    if (rc == LMH_OK) rc = lmh_set_refs_stance(h, 5.0, 2);
+    if (rc == LMH_OK) {                                             // constant foot references at (0, -/+0.05, 0)
+        double r[24] = {0}, l[24] = {0};
+        int32_t n[3] = {6, 6, 8};
+        r[8] = -0.05; l[8] = 0.05;
+        rc = lmh_set_foot_coeffs(h, r, n, l, n);
+    }
+    if (rc != LMH_OK) { std::string keep = g_err; lmh_destroy(h); *out = nullptr; g_err = keep; return rc; }
+    return LMH_OK;
+}
+
+extern "C" int lmh_destroy(lmh_handle *h)
+{
+    if (!h) return LMH_OK;
+    (void)hipSetDevice(h->device);
+    void *bufs[] = {h->d_model, h->d_mpc, h->d_zx, h->d_zy, h->d_gcol, h->d_raw, h->d_phase, h->d_state, h->d_out, h->d_status, h->d_tgt};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    delete h;
+    return LMH_OK;
+}
+
+extern "C" int lmh_num_instances(const lmh_handle *h) { return h ? h->B : 0; }
+extern "C" int lmh_horizon(const lmh_handle *h) { return h ? h->N : 0; }
+
+extern "C" int lmh_set_model(lmh_handle *h, const double *raw, int n_models)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    if (!raw) { raw = &kLmhNaoLinks[0][0]; n_models = 1; }
+    if (n_models != 1 && n_models != h->B) return fail(LMH_ERR_BAD_ARG, "n_models must be 1 or n_instances");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->d_raw) { HIPCHK(hipFree(h->d_raw)); h->d_raw = nullptr; }
+    if (h->d_model) { HIPCHK(hipFree(h->d_model)); h->d_model = nullptr; }
+    const size_t rawb = sizeof(double) * 28 * LMH_LINK_STRIDE * (size_t)n_models;
+    HIPCHK(hipMalloc(&h->d_raw, rawb));
+    HIPCHK(hipMalloc(&h->d_model, sizeof(double) * LMH_MODEL_STRIDE * (size_t)n_models));
+    HIPCHK(hipMemcpy(h->d_raw, raw, rawb, hipMemcpyHostToDevice));
+    lmh_launch_model(h->d_raw, h->d_model, n_models, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    h->n_models = n_models;
+    fill_params(h);
+    return LMH_OK;
+}
+
+extern "C" int lmh_get_mass(lmh_handle *h, double *mass)
+{
+    if (!h || !mass) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    for (int i = 0; i < h->n_models; i++)
+        HIPCHK(hipMemcpy(mass + i, h->d_model + (size_t)i * LMH_MODEL_STRIDE + 392, sizeof(double), hipMemcpyDeviceToHost));
+    return LMH_OK;
+}
+
+extern "C" int lmh_set_refs(lmh_handle *h, const double *zx, const double *zy, const uint8_t *phase, int n)
+{
+    if (!h || !zx || !zy || n < 1) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->d_zx) { HIPCHK(hipFree(h->d_zx)); h->d_zx = nullptr; }
+    if (h->d_zy) { HIPCHK(hipFree(h->d_zy)); h->d_zy = nullptr; }
+    if (h->d_phase) { HIPCHK(hipFree(h->d_phase)); h->d_phase = nullptr; }
+    HIPCHK(hipMalloc(&h->d_zx, sizeof(double) * (size_t)n));
+    HIPCHK(hipMalloc(&h->d_zy, sizeof(double) * (size_t)n));
+    HIPCHK(hipMemcpy(h->d_zx, zx, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_zy, zy, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    if (phase) {
+        HIPCHK(hipMalloc(&h->d_phase, (size_t)n));
+        HIPCHK(hipMemcpy(h->d_phase, phase, (size_t)n, hipMemcpyHostToDevice));
+    }
+    h->n_samples = n;
+    fill_params(h);
+    return LMH_OK;
+}
+
+extern "C" int lmh_set_refs_stance(lmh_handle *h, double simulation_time, int support_foot)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    const int samples = (int)((simulation_time + 0.5) / h->cfg.dt);  // zmpGeneration.cpp:41
+    if (samples < 1) return fail(LMH_ERR_BAD_ARG, "no samples");
+    std::vector<double> zx((size_t)samples, 0.0), zy((size_t)samples, (support_foot == 0) ? -0.05 : (support_foot == 1) ? 0.05 : 0.0);
+    return lmh_set_refs(h, zx.data(), zy.data(), nullptr, samples);
+}
+
+extern "C" int lmh_set_foot_coeffs(lmh_handle *h, const double *r, const int32_t *rn, const double *l, const int32_t *ln)
+{
+    if (!h || !r || !rn || !l || !ln) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    for (int a = 0; a < 3; a++) {
+        if (rn[a] < 1 || rn[a] > 8 || ln[a] < 1 || ln[a] > 8) return fail(LMH_ERR_BAD_ARG, "coefficient count must be 1..8");
+        h->P.rFn[a] = rn[a]; h->P.lFn[a] = ln[a];
+        for (int k = 0; k < 8; k++) { h->P.rF[a][k] = r[8 * a + k]; h->P.lF[a][k] = l[8 * a + k]; }
+    }
+    return LMH_OK;
+}
+
+extern "C" int lmh_set_zcom(lmh_handle *h, const double *z, int n)
+{
+    if (!h || !z || (n != 1 && n != h->B)) return fail(LMH_ERR_BAD_ARG, "n must be 1 or n_instances");
+    HIPCHK(hipSetDevice(h->device));
+    return upload_gain(h, z, n);
+}
+
+extern "C" int lmh_get_mpc_gain(lmh_handle *h, double *K)
+{
+    if (!h || !K) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    std::memcpy(K, h->h_gain.data(), sizeof(double) * (size_t)(h->N + 1));
+    return LMH_OK;
+}
+
+static int ready(lmh_handle *h)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    if (!h->d_model || !h->d_mpc || !h->d_zx) return fail(LMH_ERR_NOT_READY, "model / references not set");
+    return LMH_OK;
+}
+
+extern "C" int lmh_eval(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, void *stream)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!d_state || !d_out || !d_status) return fail(LMH_ERR_BAD_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    lmh_launch_eval(&h->P, d_state, d_out, d_status, nullptr, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return LMH_OK;
+}
+
+extern "C" int lmh_eval_debug(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, double *d_debug, void *stream)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!d_state || !d_out || !d_status || !d_debug) return fail(LMH_ERR_BAD_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    lmh_launch_eval(&h->P, d_state, d_out, d_status, d_debug, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return LMH_OK;
+}
+
+extern "C" int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, double *d_log, int n_ticks, void *stream)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!d_state || !d_out || !d_status || n_ticks < 0) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    if (n_ticks == 0) return LMH_OK;
+    HIPCHK(hipSetDevice(h->device));
+    lmh_launch_rollout(&h->P, d_state, d_out, d_status, d_log, n_ticks, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return LMH_OK;
+}
+
+extern "C" int lmh_ik(lmh_handle *h, double *d_q, const double *com_target, const double *rf6, const double *lf6, int32_t *d_iters, void *stream)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!d_q || !com_target || !rf6 || !lf6) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    double tgt[16] = {0};
+    for (int k = 0; k < 6; k++) { tgt[k] = rf6[k]; tgt[6 + k] = lf6[k]; }
+    for (int k = 0; k < 3; k++) tgt[12 + k] = com_target[k];
+    HIPCHK(hipMemcpyAsync(h->d_tgt, tgt, sizeof(tgt), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));              // tgt lives on this stack frame
+    lmh_launch_ik(&h->P, d_q, h->d_tgt, d_iters, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return LMH_OK;
+}
+
+extern "C" int lmh_eval_host(lmh_handle *h, const double *q, const double *dq, double t, double *tau, double *f, double *qdd, int32_t *status)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!q || !dq) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    // keep v_prev / active set from the previous call (Robot::v_ semantics): read-modify-write
+    for (int i = 0; i < h->B; i++) {
+        double *s = h->h_state.data() + (size_t)LMH_STATE_STRIDE * i;
+        std::memcpy(s, q + 30 * (size_t)i, 30 * sizeof(double));
+        std::memcpy(s + 30, dq + 30 * (size_t)i, 30 * sizeof(double));
+        s[90] = t;
+    }
+    HIPCHK(hipMemcpy(h->d_state, h->h_state.data(), sizeof(double) * h->h_state.size(), hipMemcpyHostToDevice));
+    lmh_launch_eval(&h->P, h->d_state, h->d_out, h->d_status, nullptr, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(h->h_state.data(), h->d_state, sizeof(double) * h->h_state.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h->h_out.data(), h->d_out, sizeof(double) * h->h_out.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h->h_status.data(), h->d_status, sizeof(int32_t) * h->h_status.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->B; i++) {
+        const double *o = h->h_out.data() + (size_t)LMH_OUT_STRIDE * i;
+        if (tau) std::memcpy(tau + 24 * (size_t)i, o, 24 * sizeof(double));
+        if (f) std::memcpy(f + 12 * (size_t)i, o + 24, 12 * sizeof(double));
+        if (qdd) std::memcpy(qdd + 30 * (size_t)i, o + 36, 30 * sizeof(double));
+        if (status) std::memcpy(status + 4 * (size_t)i, h->h_status.data() + 4 * (size_t)i, 4 * sizeof(int32_t));
+    }
+    return LMH_OK;
+}
+
+extern "C" int lmh_set_prev_velocity_host(lmh_handle *h, const double *v /*[B][30]*/)
+{
+    if (!h || !v) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    for (int i = 0; i < h->B; i++) std::memcpy(h->h_state.data() + (size_t)LMH_STATE_STRIDE * i + 60, v + 30 * (size_t)i, 30 * sizeof(double));
+    return LMH_OK;
+}
+
+extern "C" int lmh_synchronize(lmh_handle *h, void *stream)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return LMH_OK;
+}

@@ -1,0 +1,35 @@
+// lmh_device.h -- parameter block shared by the host launcher and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#define LMH_MODEL_STRIDE 400  // per model: 28 x 14 doubles (Ibar 9 | m*c 3 | m | pad) + [392] total mass
+#define LMH_BODY_STRIDE 14
+
+struct LmhDevParams {
+    // ---- device buffers
+    const double *model;        // [n_models][LMH_MODEL_STRIDE]
+    const double *mpc;          // [n_gain][mpc_stride]: K(N+1) | Px0(N+1) | Px1(N+1) | zcom | pad(3)
+    const double *zmpx;         // [n_samples]
+    const double *zmpy;
+    const uint8_t *phase;       // [n_samples] or nullptr
+    const double *gcol;         // [32][6]  friction-cone generators in wrench order (n; f)
+    int32_t model_stride;       // 0 = shared model
+    int32_t mpc_stride_inst;    // 0 = shared gain row
+    int32_t mpc_stride;         // 3*(N+1)+4
+    int32_t n_samples;
+    int32_t horizon;            // N
+    int32_t n_instances;
+    int32_t warm_start;
+    int32_t max_qp_iters;
+    // ---- scalars (reference literals, see include/lmh.h lmh_config)
+    double dt;
+    double kp_joints, kd_joints, kp_mom, kd_mom, kp_feet, kd_feet;
+    double w_com_lin, w_com_ang, w_base_pos, w_base_ang, w_joints, w_force, w_foot;
+    double eps_coeff;
+    double a00, a01, a10, a11, b0, b1;   // LIPM A, B (mpcLinearPendulum.cpp:45-47)
+    // ---- foot reference polynomials (shared), ascending powers
+    double rF[3][8];
+    double lF[3][8];
+    int32_t rFn[3];
+    int32_t lFn[3];
+};

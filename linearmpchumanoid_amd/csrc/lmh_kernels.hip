@@ -1,0 +1,1350 @@
+// lmh_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the batched NAO controller.
+//
+// ONE WAVEFRONT (64 lanes) OWNS ONE ROBOT INSTANCE.  A workgroup is exactly one wave, so
+// every "barrier" below is a wave-level fence (hipcc lowers __syncthreads() of a 64-thread
+// workgroup to a wave barrier); all per-instance working data (kinematic tree, spatial
+// inertias, mass matrix, Jacobians, QP blocks) lives in ~38 KB of LDS (4 instances per CU),
+// HBM is touched only for the 768-B state record in, the 576-B result out and the shared
+// read-only tables (model, MPC gain row, ZMP window) which stay L2-resident.
+//
+// What is evaluated (reference file:line each block follows is cited inline):
+//   Robot::updateState  -> FK, CoM, parent-relative Pluecker transforms    src/Robot.cpp
+//   Dynamics::computeAll-> C, Cg, M (CRBA), AG, AGpqp, Jdot*qdot           src/Dynamics.cpp
+//   Kinematics::computeAll -> feet Jacobian                                src/invKinematics.cpp
+//   Mpc3dLip::compute   -> u0 = -K (Px x_k - zmp[k..k+N])                  src/mpcLinearPendulum.cpp
+//   Controller::WBC     -> PD references, QP, torques                      src/controller.cpp
+//   rk4Step(dynamics)   -> closed loop                                     rk4.hpp, apps/offline/main.cpp
+//
+// The QP (74 variables, 18 equalities, 32 bounds) is solved EXACTLY but not densely:
+//   * H_aa = D + U' Om U (diagonal + rank<=18)  -> Woodbury with an 18x18 Cholesky,
+//   * the 6 floating-base rows are eliminated through the 6x6 Schur complement S,
+//   * w = G c is substituted, leaving a 32-variable bound-constrained strictly convex QP
+//     min 1/2 c'(G'WG + eps I)c - (G'h)'c, c >= 0, solved by block principal pivoting
+//     (finite, exact at termination; warm-startable from the previous active set).
+// The minimiser is unique (H is SPD), so this equals what qpOASES returns in the reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lmh_device.h"
+#include "../../include/lmh.h"
+
+#define WSYNC() __syncthreads()
+
+// ------------------------------------------------------------------ constant tables
+// Robot.cpp:162-174
+__constant__ int8_t c_parent[28] = {-1, 0, 1, 2, 3, 4, 5, 6, 0, 8, 9, 10, 11, 12, 13, 0, 15, 16, 17, 18, 0, 20, 21, 22, 23, 0, 25, 26};
+__constant__ int8_t c_act[28] = {0, 1, 2, 3, 4, 5, 6, 0, 7, 8, 9, 10, 11, 12, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 0};
+// frame -> slot of its local transform (Temp[] index of Robot.cpp:120-158; 27 = sole offset)
+__constant__ int8_t c_loc[28] = {-1, 0, 1, 2, 3, 4, 5, 27, 6, 7, 8, 9, 10, 11, 27, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24};
+// body list (frames with mass): base + 24 actuated
+__constant__ int8_t c_body[25] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26};
+// actuated joint a (0..23) -> frame
+__constant__ int8_t c_jframe[24] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26};
+// actuated joint a -> depth in its chain (1 = child of the base), limb start joint
+__constant__ int8_t c_jdepth[24] = {1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 1, 2};
+__constant__ int8_t c_jstart[24] = {0, 0, 0, 0, 0, 0, 6, 6, 6, 6, 6, 6, 12, 12, 12, 12, 12, 17, 17, 17, 17, 17, 22, 22};
+// chain c, depth d (1..7) -> frame, -1 = none (legs include the sole at depth 7)
+__constant__ int8_t c_chain[5][7] = {{1, 2, 3, 4, 5, 6, 7}, {8, 9, 10, 11, 12, 13, 14}, {15, 16, 17, 18, 19, -1, -1},
+                                     {20, 21, 22, 23, 24, -1, -1}, {25, 26, 27, -1, -1, -1, -1}};
+// FK schedule: chain c, step s -> dst, src T slot, local slot (T slots 28/29 = T0*auxT01 / T0*auxT09)
+__constant__ int8_t c_fk_dst[5][8] = {{28, 1, 2, 3, 4, 5, 6, 7}, {29, 8, 9, 10, 11, 12, 13, 14}, {15, 16, 17, 18, 19, -1, -1, -1},
+                                      {20, 21, 22, 23, 24, -1, -1, -1}, {25, 26, 27, -1, -1, -1, -1, -1}};
+__constant__ int8_t c_fk_src[5][8] = {{0, 28, 1, 2, 3, 4, 5, 6}, {0, 29, 8, 9, 10, 11, 12, 13}, {0, 15, 16, 17, 18, -1, -1, -1},
+                                      {0, 20, 21, 22, 23, -1, -1, -1}, {0, 25, 26, -1, -1, -1, -1, -1}};
+__constant__ int8_t c_fk_loc[5][8] = {{25, 0, 1, 2, 3, 4, 5, 27}, {26, 6, 7, 8, 9, 10, 11, 27}, {12, 13, 14, 15, 16, -1, -1, -1},
+                                      {17, 18, 19, 20, 21, -1, -1, -1}, {22, 23, 24, -1, -1, -1, -1, -1}};
+// Khalil modified-DH tables, Robot.cpp:180-196.  cos/sin(alpha) are the values libm returns for
+// the reference's literal pi (cos(+-pi/2) = 6.123233995736766e-17, kept: SURVEY appendix A3).
+#define CPI2 6.123233995736766e-17
+__constant__ double c_dh_r[25] = {-0.07071, 0, 0, 0, 0, 0, 0.07071, 0, 0, 0, 0, 0, 0, 0, 0.105, 0, 0.05595, 0, 0, 0.105, 0, 0.05595, 0, 0, 0};
+__constant__ double c_dh_d[25] = {0, 0, 0, -0.1, -0.1029, 0, 0, 0, 0, -0.1, -0.1029, 0, 0, 0, -0.015, 0, 0, 0, 0, -0.015, 0, 0, 0, 0, 0.030};
+__constant__ double c_dh_ca[25] = {1, CPI2, CPI2, 1, 1, CPI2, CPI2, CPI2, CPI2, 1, 1, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, 1, CPI2, 1};
+__constant__ double c_dh_sa[25] = {0, 1, 1, 0, 0, -1, -1, -1, 1, 0, 0, -1, -1, 1, 1, -1, 1, 1, 1, 1, -1, 1, 0, -1, 0};
+// theta offsets, Robot.cpp:59-87, as multiples of the reference's pi literal
+#define RPI 3.14159265358979323846
+__constant__ double c_dh_off[24] = {0, (3.0 / 4) * RPI, 0, 0, 0, 0, -(1.0 / 2) * RPI, (1.0 / 4) * RPI, 0, 0, 0, 0,
+                                    0, (1.0 / 2) * RPI, 0, 0, 0, 0, (1.0 / 2) * RPI, 0, 0, 0, 0, -(1.0 / 2) * RPI};
+// fixed transforms (3x4): auxT01, auxT09 (0.7071 literal, Robot.cpp:92-103), sole offset (:106-117)
+__constant__ double c_aux[3][12] = {{0, -1, 0, 0, 0.7071, 0, 0.7071, 0, -0.7071, 0, 0.7071, 0},
+                                    {1, 0, 0, 0, 0, 0.7071, 0.7071, 0, 0, -0.7071, 0.7071, 0},
+                                    {1, 0, 0, -0.0452, 0, 1, 0, 0, 0, 0, 1, 0}};
+// shoulder / head offsets added to the translation of Temp[12], Temp[17], Temp[22] (Robot.cpp:134-154)
+__constant__ double c_off_y[3] = {-0.098, 0.098, 0.0};
+__constant__ double c_off_z[3] = {0.13591, 0.13591, 0.1615};
+// Robot::desiredPosture, Robot.cpp:253-262
+__constant__ double c_qdes[30] = {-0.0185, 0, 0.282, 0, 0, 0, 0, 0, -0.5, 0.8, -0.3, 0, 0, 0, -0.5, 0.8, -0.3, 0,
+                                  1.6, 0, 0, 0, 0, -1.6, 0, 0, 0, 0, 0, 0};
+// Rf_q0_, Robot.cpp:28-31
+__constant__ double c_rdes[9] = {0, 0, 1, 0, -1, 0, 1, 0, 0};
+// CRBA levels: frames at chain depth 6..2 (depth 1 handled separately, parent = base)
+__constant__ int8_t c_lvl[5][5] = {{6, 13, -1, -1, -1}, {5, 12, 19, 24, -1}, {4, 11, 18, 23, -1}, {3, 10, 17, 22, -1}, {2, 9, 16, 21, 26}};
+__constant__ int8_t c_lvln[5] = {2, 4, 4, 4, 5};
+// base children in the order the reference accumulates them (i = 27 -> 1): head, LA, RA, LL, RL
+__constant__ int8_t c_roots[5] = {25, 20, 15, 8, 1};
+
+// ------------------------------------------------------------------ LDS map (doubles)
+enum {
+    P_MODEL = 0,      // 28 x 14 (+ mass at 392)
+    P_Q = 400, P_V = 430, P_VP = 460, P_TIME = 490,
+    P_VHS = 496, P_VHN = 526, P_SC = 556,
+    P_TB = 612,       // T0, T7, T14 (3 x 12)
+    P_X0 = 648,       // E0(9) p0(3) B0(9)
+    P_C = 672, P_CG = 702, P_AGPQP = 708, P_JPQP = 714, P_COM = 726, P_COMV = 729, P_ANGM = 732, P_MPC = 735,
+    P_MTOP = 744, P_HL = 924, P_JC = 1068, P_AG = 1212,
+    P_QREF = 1392, P_HREF = 1422, P_FREF = 1428, P_VFOOT = 1440,
+    P_Y = 1452,       // 30 x 7 : H^-1 [g | Mb']
+    P_SI = 1662, P_D6 = 1698, P_W = 1704, P_H12 = 1848, P_QV = 1860, P_CC = 1892, P_LAM = 1924,
+    P_W12 = 1956, P_LAM6 = 1968, P_A = 1974, P_GCOL = 2004, P_TAU = 2196, P_QDD = 2220,
+    P_END = 2252,
+    // ---- scratch, phase A1 (kinematics + Newton-Euler)
+    S0 = P_END,
+    A_LC = S0 + 0,    // 28 x 12 local transforms (dead after FK)
+    A_VEL = S0 + 0, A_ACCG = S0 + 168, A_ACC0 = S0 + 336, A_FG = S0 + 504, A_F0 = S0 + 672,
+    A_T = S0 + 840,   // 30 x 12
+    A_XE = S0 + 1200, A_XP = S0 + 1452, A_XB = S0 + 1536,
+    // ---- phase A2 (CRBA + Jacobian)
+    A_IC = S0 + 0,    // 28 x 36
+    A_YT = S0 + 1008, // 5 x 36
+    A_FB = S0 + 1788, // 2 x 24 x 6
+    A_XN = S0 + 2076, // 2 x 2 x 18
+    A_JL = S0 + 2148, // 2 x 6 x 12
+    // ---- phase B (Woodbury + Schur)
+    B_U = S0 + 0,     // 18 x 30
+    B_K = S0 + 540,   // 25 x 19
+    B_BP = S0 + 1016, // 30 x 7
+    B_S = S0 + 1226,  // 12 x 7
+    B_T1 = S0 + 1310, // 12 x 6
+    // ---- phase C (cone QP)
+    C_WG = S0 + 0,    // 12 x 32
+    C_P = S0 + 384,   // 32 x 32
+    C_PW = S0 + 1408, // 34 x 33
+    C_IDX = S0 + 2530,
+    LDS_DOUBLES = S0 + 2548
+};
+
+#define LANE ((int)threadIdx.x)
+
+// (X m)[k] for X = [E' 0; B E'],  m = [ang; lin]   (generalizedFunctions.cpp:11-19)
+__device__ __forceinline__ double x_mot(const double *E, const double *Bm, const double *m, int k)
+{
+    if (k < 3) return E[k] * m[0] + E[3 + k] * m[1] + E[6 + k] * m[2];
+    const int a = k - 3;
+    return Bm[a * 3] * m[0] + Bm[a * 3 + 1] * m[1] + Bm[a * 3 + 2] * m[2] + E[a] * m[3] + E[3 + a] * m[4] + E[6 + a] * m[5];
+}
+// (X' f)[k],  X' = [E B'; 0 E]
+__device__ __forceinline__ double x_force(const double *E, const double *Bm, const double *f, int k)
+{
+    if (k < 3) return E[k * 3] * f[0] + E[k * 3 + 1] * f[1] + E[k * 3 + 2] * f[2] + Bm[k] * f[3] + Bm[3 + k] * f[4] + Bm[6 + k] * f[5];
+    const int a = k - 3;
+    return E[a * 3] * f[3] + E[a * 3 + 1] * f[4] + E[a * 3 + 2] * f[5];
+}
+// dense X[r][c]
+__device__ __forceinline__ double x_dense(const double *E, const double *Bm, int r, int c)
+{
+    if (r < 3) return (c < 3) ? E[c * 3 + r] : 0.0;
+    return (c < 3) ? Bm[(r - 3) * 3 + c] : E[(c - 3) * 3 + (r - 3)];
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// In-place Cholesky of the leading n x n block of K (lower, row stride ld) carrying m extra
+// rows n..n+m-1 along: on exit row n+r holds (L^-1 v_r)'.  Returns a wave-uniform flag
+// (non-zero if a pivot was not positive).  n, m wave-uniform.
+__device__ int chol_aug(double *K, int ld, int n, int m)
+{
+    int bad = 0;
+    const int rows = n + m;
+    for (int j = 0; j < n; j++) {
+        WSYNC();
+        const double d = K[j * ld + j];
+        if (!(d > 0.0)) bad = 1;
+        const double invd = 1.0 / d;
+        const int nr = rows - j - 1;          // rows below the pivot
+        const int nc = n - j - 1;             // columns right of the pivot
+        // trailing update with the UNSCALED pivot column: K[i][c] -= K[i][j] K[c][j] / d   (c <= i when i < n)
+        for (int e = LANE; e < nr * nc; e += 64) {
+            const int i = j + 1 + e / nc, c = j + 1 + e % nc;
+            if (i >= n || c <= i) K[i * ld + c] -= K[i * ld + j] * K[c * ld + j] * invd;
+        }
+        WSYNC();
+        const double s = sqrt(d), invs = 1.0 / s;
+        for (int i = j + 1 + LANE; i < rows; i += 64) K[i * ld + j] *= invs;
+        if (LANE == 0) K[j * ld + j] = s;
+    }
+    WSYNC();
+    return bad;
+}
+// Solve L' t = y in place for the m extra rows (each a length-n vector stored in row n+r).
+__device__ void chol_back(double *K, int ld, int n, int m)
+{
+    for (int j = n - 1; j >= 0; j--) {
+        WSYNC();
+        const double inv = 1.0 / K[j * ld + j];
+        // t_j = y_j / L_jj ; y_i -= L[j][i] t_j  (i < j)
+        for (int e = LANE; e < m * j; e += 64) {
+            const int r = e / j, i = e % j;
+            K[(n + r) * ld + i] -= K[j * ld + i] * (K[(n + r) * ld + j] * inv);
+        }
+        WSYNC();
+        for (int r = LANE; r < m; r += 64) K[(n + r) * ld + j] *= inv;
+    }
+    WSYNC();
+}
+
+// ============================================================================ kinematics
+// Robot::forwardKinematics + matTrans + eulerAnglesToSO3 (Robot.cpp:45-160,176-223,
+// generalizedFunctions.cpp:52-72).  Reads L[P_Q], writes A_T (30 x 3x4) and L[P_SC].
+__device__ void phase_fk(double *L)
+{
+    const int lane = LANE;
+    if (lane < 28) {
+        double s, c;
+        if (lane < 24) sincos(L[P_Q + 6 + lane] + c_dh_off[lane], &s, &c);
+        else if (lane == 24) { s = -1.0; c = CPI2; }              // theta[24] = -pi/2 (Robot.cpp:87)
+        else sincos(L[P_Q + 3 + (lane - 25)], &s, &c);            // roll, pitch, yaw
+        L[P_SC + 2 * lane] = s;
+        L[P_SC + 2 * lane + 1] = c;
+    }
+    WSYNC();
+    for (int e = lane; e < 28 * 12; e += 64) {
+        const int s = e / 12, el = e % 12, r = el >> 2, col = el & 3;
+        double val;
+        if (s < 25) {
+            const double st = L[P_SC + 2 * s], ct = L[P_SC + 2 * s + 1];
+            const double ca = c_dh_ca[s], sa = c_dh_sa[s], dd = c_dh_d[s], rr = c_dh_r[s];
+            if (r == 0) val = (col == 0) ? ct : (col == 1) ? -st : (col == 2) ? 0.0 : dd;
+            else if (r == 1) val = (col == 0) ? ca * st : (col == 1) ? ca * ct : (col == 2) ? -sa : -rr * sa;
+            else val = (col == 0) ? sa * st : (col == 1) ? sa * ct : (col == 2) ? ca : rr * ca;
+            if (col == 3 && (s == 12 || s == 17 || s == 22)) {
+                const int o = (s == 12) ? 0 : (s == 17) ? 1 : 2;
+                if (r == 0) val = val + 0.0;
+                else if (r == 1) val = val + c_off_y[o];
+                else val = val + c_off_z[o];
+            }
+        } else {
+            val = c_aux[s - 25][el];
+        }
+        L[A_LC + e] = val;
+    }
+    if (lane < 12) {                                               // T0 = [R(rpy) p]
+        const int r = lane >> 2, col = lane & 3;
+        const double sr = L[P_SC + 50], cr = L[P_SC + 51], sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
+        double val;
+        if (col == 3) val = L[P_Q + r];
+        else if (r == 0) val = (col == 0) ? cy * cp : (col == 1) ? cy * sp * sr - sy * cr : cy * sp * cr + sy * sr;
+        else if (r == 1) val = (col == 0) ? sy * cp : (col == 1) ? sy * sp * sr + cy * cr : sy * sp * cr - cy * sr;
+        else val = (col == 0) ? -sp : (col == 1) ? cp * sr : cp * cr;
+        L[A_T + lane] = val;
+    }
+    const int c = lane / 12, el = lane % 12, r = el >> 2, col = el & 3;
+    for (int s = 0; s < 8; s++) {
+        WSYNC();
+        if (lane < 60) {
+            const int dst = c_fk_dst[c][s];
+            if (dst >= 0) {
+                const double *Ts = L + A_T + 12 * c_fk_src[c][s] + 4 * r;
+                const double *Lo = L + A_LC + 12 * c_fk_loc[c][s] + col;
+                double val = Ts[0] * Lo[0] + Ts[1] * Lo[4] + Ts[2] * Lo[8];
+                if (col == 3) val += Ts[3];
+                L[A_T + 12 * dst + el] = val;
+            }
+        }
+    }
+    WSYNC();
+}
+
+// Robot::computeCoM (Robot.cpp:225-238) + parentTransMatrix/allVelocityMatrices/velocityMatrix
+// (Robot.cpp:276-298, generalizedFunctions.cpp:11-27: R' used as inverse, kept).
+__device__ void phase_com_x(double *L)
+{
+    const int lane = LANE;
+    double cx = 0, cy = 0, cz = 0;
+    if (lane < 28) {
+        const double *T = L + A_T + 12 * lane, *mo = L + P_MODEL + LMH_BODY_STRIDE * lane;
+        const double m = mo[12];
+        if (m != 0.0) {
+            // joint-frame com = (m c)/m is not stored; the model keeps m*c, so use it directly
+            cx = T[0] * mo[9] + T[1] * mo[10] + T[2] * mo[11] + m * T[3];
+            cy = T[4] * mo[9] + T[5] * mo[10] + T[6] * mo[11] + m * T[7];
+            cz = T[8] * mo[9] + T[9] * mo[10] + T[10] * mo[11] + m * T[11];
+        }
+    }
+    cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
+    if (lane == 0) {
+        const double mass = L[P_MODEL + 392];
+        L[P_COM] = cx / mass; L[P_COM + 1] = cy / mass; L[P_COM + 2] = cz / mass;
+    }
+    for (int e = lane; e < 28 * 12; e += 64) {
+        const int i = e / 12, el = e % 12;
+        const double *Ti = L + A_T + 12 * i;
+        double val;
+        if (i == 0) {
+            val = (el < 9) ? Ti[(el / 3) * 4 + el % 3] : Ti[(el - 9) * 4 + 3];
+        } else {
+            const double *Tp = L + A_T + 12 * c_parent[i];
+            if (el < 9) {
+                const int a = el / 3, b = el % 3;
+                val = Tp[a] * Ti[b] + Tp[4 + a] * Ti[4 + b] + Tp[8 + a] * Ti[8 + b];
+            } else {
+                const int a = el - 9;
+                const double pa = Tp[a] * Ti[3] + Tp[4 + a] * Ti[7] + Tp[8 + a] * Ti[11];
+                const double pb = (-Tp[a]) * Tp[3] + (-Tp[4 + a]) * Tp[7] + (-Tp[8 + a]) * Tp[11];
+                val = pa + pb;
+            }
+        }
+        if (el < 9) L[A_XE + 9 * i + el] = val;
+        else L[A_XP + 3 * i + (el - 9)] = val;
+    }
+    WSYNC();
+    for (int e = lane; e < 28 * 9; e += 64) {
+        const int i = e / 9, a = (e % 9) / 3, b = e % 3;
+        const double *E = L + A_XE + 9 * i, *p = L + A_XP + 3 * i;
+        double val;                                               // B = (-E') [p]x
+        if (b == 0) val = (-E[3 + a]) * p[2] + E[6 + a] * p[1];
+        else if (b == 1) val = E[a] * p[2] + (-E[6 + a]) * p[0];
+        else val = (-E[a]) * p[1] + E[3 + a] * p[0];
+        L[A_XB + e] = val;
+    }
+    WSYNC();
+    // persistent copies: T0, T7, T14, X0
+    if (lane < 36) L[P_TB + lane] = L[A_T + 12 * ((lane < 12) ? 0 : (lane < 24) ? 7 : 14) + lane % 12];
+    if (lane < 21) L[P_X0 + lane] = (lane < 9) ? L[A_XE + lane] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XB + lane - 12];
+    // base-frame reordered velocities, stale (Robot::v_) and fresh: swapBaseVelocityAndRefToWorldFrame
+    if (lane < 60) {
+        const int which = lane / 30, i = lane % 30;
+        const double *v = L + (which ? P_V : P_VP);
+        double val;
+        if (i < 6) {
+            const double m[6] = {v[3], v[4], v[5], v[0], v[1], v[2]};
+            val = x_mot(L + A_XE, L + A_XB, m, i);
+        } else val = v[i];
+        L[(which ? P_VHN : P_VHS) + i] = val;
+    }
+    WSYNC();
+}
+
+// Dynamics::computeC (gravity / no gravity) + computeJpqpFrame(7),(14): forward and backward
+// Newton-Euler with qdd = 0 on the STALE velocity (Dynamics.cpp:29-60,124-200).
+__device__ void phase_newton_euler(double *L)
+{
+    const int lane = LANE;
+    // base: vel0 = vhat[0:6]; accg0 = X0 * [0 0 0 0 0 9.81]; acc00 = 0
+    if (lane < 6) {
+        L[A_VEL + lane] = L[P_VHS + lane];
+        const double g[6] = {0, 0, 0, 0, 0, 9.81};
+        L[A_ACCG + lane] = x_mot(L + A_XE, L + A_XB, g, lane);
+        L[A_ACC0 + lane] = 0.0;
+    }
+    {   // velocity sweep, lanes (chain, k)
+        const int c = lane / 6, k = lane % 6;
+        for (int d = 0; d < 6; d++) {
+            WSYNC();
+            if (lane < 30) {
+                const int i = c_chain[c][d];
+                if (i >= 0 && c_act[i] != 0) {
+                    const double *vp = L + A_VEL + 6 * c_parent[i];
+                    double val = x_mot(L + A_XE + 9 * i, L + A_XB + 9 * i, vp, k);
+                    if (k == 2) val += L[P_VHS + 5 + c_act[i]];
+                    L[A_VEL + 6 * i + k] = val;
+                }
+            }
+        }
+    }
+    {   // acceleration sweeps (with / without gravity), lanes (chain, which, k); includes the soles
+        const int c = lane / 12, which = (lane % 12) / 6, k = lane % 6;
+        const int base = which ? A_ACC0 : A_ACCG;
+        for (int d = 0; d < 7; d++) {
+            WSYNC();
+            if (lane < 60) {
+                const int i = c_chain[c][d];
+                if (i >= 0 && !(c == 4 && d == 2)) {
+                    const double *ap = L + base + 6 * c_parent[i];
+                    double val = x_mot(L + A_XE + 9 * i, L + A_XB + 9 * i, ap, k);
+                    if (c_act[i] != 0) {
+                        const double *vi = L + A_VEL + 6 * i;
+                        const double qd = L[P_VHS + 5 + c_act[i]];
+                        // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
+                        const double cs = (k == 0) ? vi[1] : (k == 1) ? -vi[0] : (k == 3) ? vi[4] : (k == 4) ? -vi[3] : 0.0;
+                        val += cs * qd;
+                    }
+                    L[base + 6 * i + k] = val;
+                }
+            }
+        }
+    }
+    WSYNC();
+    // body forces f = I a + v x* (I v), one lane per (body, which)
+    if (lane < 50) {
+        const int which = lane / 25, i = c_body[lane % 25];
+        const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
+        const double *v = L + A_VEL + 6 * i, *a = L + (which ? A_ACC0 : A_ACCG) + 6 * i;
+        const double m = mo[12], hx = mo[9], hy = mo[10], hz = mo[11];
+        // I a
+        double n0 = mo[0] * a[0] + mo[1] * a[1] + mo[2] * a[2] + (hy * a[5] - hz * a[4]);
+        double n1 = mo[3] * a[0] + mo[4] * a[1] + mo[5] * a[2] + (hz * a[3] - hx * a[5]);
+        double n2 = mo[6] * a[0] + mo[7] * a[1] + mo[8] * a[2] + (hx * a[4] - hy * a[3]);
+        double f0 = m * a[3] - (hy * a[2] - hz * a[1]);
+        double f1 = m * a[4] - (hz * a[0] - hx * a[2]);
+        double f2 = m * a[5] - (hx * a[1] - hy * a[0]);
+        // I v
+        const double p0 = mo[0] * v[0] + mo[1] * v[1] + mo[2] * v[2] + (hy * v[5] - hz * v[4]);
+        const double p1 = mo[3] * v[0] + mo[4] * v[1] + mo[5] * v[2] + (hz * v[3] - hx * v[5]);
+        const double p2 = mo[6] * v[0] + mo[7] * v[1] + mo[8] * v[2] + (hx * v[4] - hy * v[3]);
+        const double l0 = m * v[3] - (hy * v[2] - hz * v[1]);
+        const double l1 = m * v[4] - (hz * v[0] - hx * v[2]);
+        const double l2 = m * v[5] - (hx * v[1] - hy * v[0]);
+        // v x* (p; l) = (w x p + vl x l ; w x l)
+        n0 += (v[1] * p2 - v[2] * p1) + (v[4] * l2 - v[5] * l1);
+        n1 += (v[2] * p0 - v[0] * p2) + (v[5] * l0 - v[3] * l2);
+        n2 += (v[0] * p1 - v[1] * p0) + (v[3] * l1 - v[4] * l0);
+        f0 += (v[1] * l2 - v[2] * l1);
+        f1 += (v[2] * l0 - v[0] * l2);
+        f2 += (v[0] * l1 - v[1] * l0);
+        double *fo = L + (which ? A_F0 : A_FG) + 6 * i;
+        fo[0] = n0; fo[1] = n1; fo[2] = n2; fo[3] = f0; fo[4] = f1; fo[5] = f2;
+    }
+    {   // backward sweep, lanes (chain, which, k): depth 6 -> 2 accumulate into the parent
+        const int c = lane / 12, which = (lane % 12) / 6, k = lane % 6;
+        const int base = which ? A_F0 : A_FG;
+        for (int d = 5; d >= 1; d--) {
+            WSYNC();
+            if (lane < 60) {
+                const int i = c_chain[c][d];
+                if (i >= 0 && c_act[i] != 0) {
+                    const int p = c_parent[i];
+                    L[base + 6 * p + k] += x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + base + 6 * i, k);
+                }
+            }
+        }
+        WSYNC();
+        if (lane < 12) {                                           // base, reference order head, LA, RA, LL, RL
+            const int w2 = lane / 6, k2 = lane % 6, b2 = w2 ? A_F0 : A_FG;
+            double acc = L[b2 + k2];
+            for (int r = 0; r < 5; r++) {
+                const int i = c_roots[r];
+                acc += x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + b2 + 6 * i, k2);
+            }
+            if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc;
+        }
+        if (lane >= 16 && lane < 40) L[P_C + 6 + (lane - 16)] = L[A_FG + 6 * c_jframe[lane - 16] + 2];
+        if (lane >= 40 && lane < 52) {                             // Jpqp = blkdiag(R,R) acc0[sole]
+            const int foot = (lane - 40) / 6, k2 = (lane - 40) % 6, r = k2 % 3, o = (k2 / 3) * 3;
+            const double *T = L + P_TB + 12 * (1 + foot), *a = L + A_ACC0 + 6 * (foot ? 14 : 7);
+            L[P_JPQP + 6 * foot + k2] = T[4 * r] * a[o] + T[4 * r + 1] * a[o + 1] + T[4 * r + 2] * a[o + 2];
+        }
+    }
+    WSYNC();
+}
+
+// Dynamics::computeM (CRBA, Dynamics.cpp:62-101) -> Mtop = [Ic0 | F2], Hl (per-limb joint blocks)
+__device__ void phase_crba(double *L)
+{
+    const int lane = LANE;
+    // composite inertias start as the body inertias: [Ibar, [h]x; -[h]x, m 1]   (Dynamics.cpp:4-13)
+    for (int e = lane; e < 25 * 36; e += 64) {
+        const int i = c_body[e / 36], r = (e % 36) / 6, c = e % 6;
+        const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
+        double val;
+        if (r < 3 && c < 3) val = mo[3 * r + c];
+        else if (r >= 3 && c >= 3) val = (r == c) ? mo[12] : 0.0;
+        else {
+            const int a = r % 3, b = c % 3;                        // [h]x(a,b)
+            double cm = 0.0;
+            if (a != b) {
+                const int k = 3 - a - b;
+                cm = (((b - a + 3) % 3) == 2) ? mo[9 + k] : -mo[9 + k];   // (0,2)=+hy? see below
+            }
+            // [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]: (a,b) with b = a+1 (mod 3) -> -h_k, b = a+2 -> +h_k
+            val = (r < 3) ? cm : -cm;
+        }
+        L[A_IC + 36 * i + 6 * r + c] = val;
+    }
+    for (int lv = 0; lv < 5; lv++) {
+        const int nf = c_lvln[lv];
+        WSYNC();
+        for (int e = lane; e < nf * 36; e += 64) {                 // Y = Ic_i X_i
+            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = c_lvl[lv][sl];
+            const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
+            double s = 0.0;
+            if (c < 3) { for (int k = 0; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
+            else { for (int k = 3; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
+            L[A_YT + e] = s;
+        }
+        WSYNC();
+        for (int e = lane; e < nf * 36; e += 64) {                 // Ic_parent += X_i' Y
+            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = c_lvl[lv][sl];
+            const double *Y = L + A_YT + 36 * sl + c, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
+            double s = 0.0;
+            if (r < 3) { for (int k = 0; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
+            else { for (int k = 3; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
+            L[A_IC + 36 * c_parent[i] + 6 * r + c] += s;
+        }
+    }
+    WSYNC();
+    for (int e = lane; e < 5 * 36; e += 64) {                      // depth-1 frames: Y
+        const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = c_roots[sl];
+        const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
+        double s = 0.0;
+        if (c < 3) { for (int k = 0; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
+        else { for (int k = 3; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
+        L[A_YT + e] = s;
+    }
+    WSYNC();
+    if (lane < 36) {                                               // Ic0 += sum in reference order
+        const int r = lane / 6, c = lane % 6;
+        double acc = L[A_IC + lane];
+        for (int sl = 0; sl < 5; sl++) {
+            const int i = c_roots[sl];
+            const double *Y = L + A_YT + 36 * sl + c, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
+            double s = 0.0;
+            if (r < 3) { for (int k = 0; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
+            else { for (int k = 3; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
+            acc += s;
+        }
+        L[P_MTOP + 30 * r + c] = acc;
+    }
+    // joint columns: f = Ic_i S, walked up the chain (Dynamics.cpp:83-93)
+    for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
+    for (int e = lane; e < 144; e += 64) {
+        const int a = e / 6, k = e % 6;
+        L[A_FB + e] = L[A_IC + 36 * c_jframe[a] + 6 * k + 2];
+    }
+    WSYNC();
+    if (lane < 24) L[P_HL + 6 * lane + (lane - c_jstart[lane])] = L[A_FB + 6 * lane + 2];
+    int cur = 0;
+    for (int s = 1; s <= 6; s++) {
+        WSYNC();
+        for (int e = lane; e < 144; e += 64) {
+            const int a = e / 6, k = e % 6, dpt = c_jdepth[a];
+            if (s <= dpt) {
+                const int j = c_jframe[a] - (s - 1);               // frame whose X' is applied
+                const double val = x_force(L + A_XE + 9 * j, L + A_XB + 9 * j, L + A_FB + 144 * cur + 6 * a, k);
+                L[A_FB + 144 * (cur ^ 1) + e] = val;
+                if (s == dpt) L[P_MTOP + 30 * k + 6 + a] = val;    // F2 column
+                else if (k == 2) {
+                    const int aj = a - s;                          // joint of parent(j)
+                    L[P_HL + 6 * aj + (a - c_jstart[a])] = val;
+                    L[P_HL + 6 * a + (aj - c_jstart[a])] = val;
+                }
+            }
+        }
+        cur ^= 1;
+    }
+    WSYNC();
+}
+
+// Kinematics::feetJacobian / frameJacobian (invKinematics.cpp:72-149), chain products in the
+// reference's association ((X7 X6) X5 ...); X kept as (A, B) with X = [A 0; B A].
+__device__ void phase_jacobian(double *L)
+{
+    const int lane = LANE;
+    const int foot = lane / 18, el = lane % 18, half = el / 9, r = (el % 9) / 3, c = el % 3;
+    const int sole = foot ? 14 : 7;
+    if (lane < 36) {                                               // Xn = X_sole : A = E', B
+        L[A_XN + 36 * 0 + 18 * foot + el] = half ? L[A_XB + 9 * sole + 3 * r + c] : L[A_XE + 9 * sole + 3 * c + r];
+    }
+    int cur = 0;
+    for (int s = 0; s < 6; s++) {
+        WSYNC();
+        const int f = sole - 1 - s;                                // frame 6..1 / 13..8
+        if (lane < 36) {
+            const double *An = L + A_XN + 36 * cur + 18 * foot, *Bn = An + 9;
+            const double *E = L + A_XE + 9 * f, *Bf = L + A_XB + 9 * f;
+            if (c == 2) L[A_JL + 72 * foot + 12 * (3 * half + r) + 6 + (5 - s)] = (half ? Bn : An)[3 * r + 2];   // Xn S
+            double val;                                            // A_f[k][c] = E[c][k]
+            if (!half) val = An[3 * r] * E[3 * c] + An[3 * r + 1] * E[3 * c + 1] + An[3 * r + 2] * E[3 * c + 2];
+            else val = Bn[3 * r] * E[3 * c] + Bn[3 * r + 1] * E[3 * c + 1] + Bn[3 * r + 2] * E[3 * c + 2]
+                     + An[3 * r] * Bf[c] + An[3 * r + 1] * Bf[3 + c] + An[3 * r + 2] * Bf[6 + c];
+            L[A_XN + 36 * (cur ^ 1) + 18 * foot + el] = val;
+        }
+        cur ^= 1;
+    }
+    WSYNC();
+    if (lane < 36) {                                               // base block [A 0; B A]
+        const double *An = L + A_XN + 36 * cur + 18 * foot, *Bn = An + 9;
+        if (!half) { L[A_JL + 72 * foot + 12 * r + c] = An[3 * r + c]; L[A_JL + 72 * foot + 12 * r + 3 + c] = 0.0; L[A_JL + 72 * foot + 12 * (3 + r) + 3 + c] = An[3 * r + c]; }
+        else L[A_JL + 72 * foot + 12 * (3 + r) + c] = Bn[3 * r + c];
+    }
+    WSYNC();
+    for (int e = lane; e < 144; e += 64) {                         // rotate to world axes
+        const int ft = e / 72, rr = (e % 72) / 12, col = e % 12, r3 = rr % 3, o = (rr / 3) * 3;
+        const double *T = L + P_TB + 12 * (1 + ft), *J = L + A_JL + 72 * ft + col;
+        L[P_JC + e] = T[4 * r3] * J[12 * o] + T[4 * r3 + 1] * J[12 * (o + 1)] + T[4 * r3 + 2] * J[12 * (o + 2)];
+    }
+    WSYNC();
+}
+
+// J[row][col] of the dense 12 x 30 feet Jacobian from the compact store
+__device__ __forceinline__ double jdense(const double *L, int row, int col)
+{
+    const int ft = row / 6, rr = row % 6;
+    if (col < 6) return L[P_JC + 72 * ft + 12 * rr + col];
+    const int j = col - 6 - 6 * ft;
+    return (j >= 0 && j < 6) ? L[P_JC + 72 * ft + 12 * rr + 6 + j] : 0.0;
+}
+
+// Dynamics::centroidalMatrixAndBias (Dynamics.cpp:103-121), Robot::computeComMomentum
+// (Robot.cpp:300-310), Mpc3dLip::compute (mpcLinearPendulum.cpp:78-109), PD references
+// (controller.cpp:296-386).
+__device__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, int *k_out, int *phase_out)
+{
+    const int lane = LANE;
+    int flags = 0;
+    const double mass = L[P_MODEL + 392];
+    for (int e = lane; e < 180; e += 64) {
+        const int r = e / 30, c = e % 30;
+        const double *T0 = L + P_TB, *Mt = L + P_MTOP + c;
+        double val;
+        if (r < 3) {
+            const double p0 = L[P_MTOP + 30 * 2 + 4] / mass, p1 = L[P_MTOP + 30 * 0 + 5] / mass, p2 = L[P_MTOP + 30 * 1 + 3] / mass;
+            // U = -(R0 [p1G]x): U[r][0] = -(R[r][1] p2 - R[r][2] p1) ...
+            const double R0 = T0[4 * r], R1 = T0[4 * r + 1], R2 = T0[4 * r + 2];
+            const double u0 = -(R1 * p2 + R2 * (-p1)), u1 = -(R0 * (-p2) + R2 * p0), u2 = -(R0 * p1 + R1 * (-p0));
+            val = R0 * Mt[0] + R1 * Mt[30] + R2 * Mt[60] + u0 * Mt[90] + u1 * Mt[120] + u2 * Mt[150];
+        } else {
+            const int a = r - 3;
+            val = T0[4 * a] * Mt[90] + T0[4 * a + 1] * Mt[120] + T0[4 * a + 2] * Mt[150];
+        }
+        L[P_AG + e] = val;
+    }
+    if (lane < 6) {                                                // AGpqp = X1G Cg[0:6]
+        const double *T0 = L + P_TB, *cg = L + P_CG;
+        const int r = lane % 3;
+        double val;
+        if (lane < 3) {
+            const double p0 = L[P_MTOP + 30 * 2 + 4] / mass, p1 = L[P_MTOP + 30 * 0 + 5] / mass, p2 = L[P_MTOP + 30 * 1 + 3] / mass;
+            const double R0 = T0[4 * r], R1 = T0[4 * r + 1], R2 = T0[4 * r + 2];
+            const double u0 = -(R1 * p2 + R2 * (-p1)), u1 = -(R0 * (-p2) + R2 * p0), u2 = -(R0 * p1 + R1 * (-p0));
+            val = R0 * cg[0] + R1 * cg[1] + R2 * cg[2] + u0 * cg[3] + u1 * cg[4] + u2 * cg[5];
+        } else val = T0[4 * r] * cg[3] + T0[4 * r + 1] * cg[4] + T0[4 * r + 2] * cg[5];
+        L[P_AGPQP + lane] = val;
+    }
+    WSYNC();
+    if (lane < 6) {                                                // h = AG vhat (fresh velocity)
+        double s = 0.0;
+        for (int c = 0; c < 30; c++) s += L[P_AG + 30 * lane + c] * L[P_VHN + c];
+        if (lane < 3) L[P_ANGM + lane] = s; else L[P_COMV + lane - 3] = s / mass;
+    }
+    if (lane >= 8 && lane < 20) {                                  // foot velocities J vhat
+        const int row = lane - 8, ft = row / 6;
+        const double *J = L + P_JC + 72 * ft + 12 * (row % 6);
+        double s = 0.0;
+        for (int c = 0; c < 6; c++) s += J[c] * L[P_VHN + c];
+        for (int c = 0; c < 6; c++) s += J[6 + c] * L[P_VHN + 6 + 6 * ft + c];
+        L[P_VFOOT + row] = s;
+    }
+    if (lane >= 32 && lane < 62) {                                 // PDJointsAcc, controller.cpp:296-308
+        const int i = lane - 32;
+        const double val = P.kp_joints * (c_qdes[i] - L[P_Q + i]) + P.kd_joints * (0.0 - L[P_V + i]);
+        L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
+    }
+    WSYNC();
+    // ---- MPC: u0 = -K (Px x_k - z[k : k+N+1])
+    const int N = P.horizon;
+    const int k = (int)(t / P.dt);                                 // mpcLinearPendulum.cpp:92 (fp64, same op order)
+    if (k < 0 || k + N >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;
+    const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
+    const double zcom = mp[3 * (N + 1)];
+    {
+        const double cxp = L[P_COM], cyp = L[P_COM + 1], vxp = L[P_COMV], vyp = L[P_COMV + 1];
+        double sx = 0.0, sy = 0.0;
+        for (int i = lane; i <= N; i += 64) {
+            int kk = k + i;
+            kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
+            const double K = mp[i], px0 = mp[(N + 1) + i], px1 = mp[2 * (N + 1) + i];
+            sx += K * ((px0 * cxp + px1 * vxp) - P.zmpx[kk]);
+            sy += K * ((px0 * cyp + px1 * vyp) - P.zmpy[kk]);
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy);
+        const double ux = -sx, uy = -sy;
+        if (lane == 0) {
+            L[P_MPC + 0] = ux; L[P_MPC + 1] = uy;
+            L[P_MPC + 2] = P.a00 * cxp + P.a01 * vxp + P.b0 * ux;   // xRef pos, vel, acc
+            L[P_MPC + 3] = P.a10 * cxp + P.a11 * vxp + P.b1 * ux;
+            L[P_MPC + 4] = ux;
+            L[P_MPC + 5] = P.a00 * cyp + P.a01 * vyp + P.b0 * uy;
+            L[P_MPC + 6] = P.a10 * cyp + P.a11 * vyp + P.b1 * uy;
+            L[P_MPC + 7] = uy;
+        }
+    }
+    int ph = 0;
+    if (P.phase) { int kk = (k < 0) ? 0 : (k >= P.n_samples ? P.n_samples - 1 : k); ph = P.phase[kk]; }
+    *k_out = k; *phase_out = ph;
+    WSYNC();
+    if (lane < 3) {                                                // PDMomentumAcc, controller.cpp:310-325
+        const double posRef = (lane == 0) ? L[P_MPC + 2] : (lane == 1) ? L[P_MPC + 5] : zcom;
+        const double velRef = (lane == 0) ? L[P_MPC + 3] : (lane == 1) ? L[P_MPC + 6] : 0.0;
+        const double accRef = (lane == 0) ? L[P_MPC + 4] : (lane == 1) ? L[P_MPC + 7] : 0.0;
+        L[P_HREF + 3 + lane] = mass * (P.kp_mom * (posRef - L[P_COM + lane]) + P.kd_mom * (velRef - L[P_COMV + lane]) + accRef);
+        L[P_HREF + lane] = P.kd_mom * (0.0 - L[P_ANGM + lane]);
+    }
+    if (lane >= 8 && lane < 10) {                                  // orientation error, controller.cpp:344-353
+        const int ft = lane - 8;
+        const double *T = L + P_TB + 12 * (1 + ft);
+        double err[9];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) err[3 * a + b] = c_rdes[a] * T[b] + c_rdes[3 + a] * T[4 + b] + c_rdes[6 + a] * T[8 + b];
+        const double tr = err[0] + err[4] + err[8];
+        const double cc = fmax(-1.0, fmin(1.0, (tr - 1.0) / 2.0));
+        const double phi = acos(cc);
+        const double v0 = err[7] - err[5], v1 = err[2] - err[6], v2 = err[3] - err[1];
+        const double sc = (phi < 1e-6) ? 0.5 : (phi / (2.0 * sin(phi)));
+        const double r0 = sc * v0, r1 = sc * v1, r2 = sc * v2;
+        for (int a = 0; a < 3; a++) {
+            const double e = -(c_rdes[3 * a] * r0 + c_rdes[3 * a + 1] * r1 + c_rdes[3 * a + 2] * r2);
+            L[P_FREF + 6 * ft + a] = P.kp_feet * e + P.kd_feet * (0.0 - L[P_VFOOT + 6 * ft + a]) + 0.0;
+        }
+    }
+    if (lane >= 16 && lane < 22) {                                 // position part, polynomials (polyval/polyder)
+        const int ft = (lane - 16) / 3, ax = (lane - 16) % 3;
+        const double *co = ft ? P.lF[ax] : P.rF[ax];
+        const int n = ft ? P.lFn[ax] : P.rFn[ax];
+        double pv = 0, xp = 1;
+        for (int i = 0; i < n; i++) { pv += co[i] * xp; xp *= t; }
+        double vv = 0; xp = 1;
+        if (n > 1) for (int i = 0; i < n - 1; i++) { vv += ((i + 1) * co[i + 1]) * xp; xp *= t; }
+        double av = 0; xp = 1;
+        if (n > 2) for (int i = 0; i < n - 2; i++) { av += ((i + 1) * ((i + 2) * co[i + 2])) * xp; xp *= t; }
+        const double pe = pv - L[P_TB + 12 * (1 + ft) + 4 * ax + 3];
+        const double ve = vv - L[P_VFOOT + 6 * ft + 3 + ax];
+        L[P_FREF + 6 * ft + 3 + ax] = P.kp_feet * pe + P.kd_feet * ve + av;
+    }
+    WSYNC();
+    return flags;
+}
+
+// Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
+__device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out)
+{
+    const int lane = LANE;
+    int flags = 0;
+    // ---- rows of U = [AG ; J] with weights Om, skipping zero-weight rows
+    const int r0 = (P.w_com_ang == 0.0) ? 3 : 0;
+    const int nU = 18 - r0;
+    for (int e = lane; e < nU * 30; e += 64) {
+        const int r = r0 + e / 30, c = e % 30;
+        L[B_U + e] = (r < 6) ? L[P_AG + 30 * r + c] : jdense(L, r - 6, c);
+    }
+    WSYNC();
+    // ---- bp = D^-1 [g_a | Mb'] ; g_a = U' Om beta - D qref   (controller.cpp:127-132)
+    for (int e = lane; e < 210; e += 64) {
+        const int i = e / 7, cidx = e % 7;
+        const double Di = (i < 3) ? P.w_base_pos : (i < 6) ? P.w_base_ang : P.w_joints;
+        double val;
+        if (cidx == 0) {
+            double s = 0.0;
+            for (int r = 0; r < nU; r++) {
+                const int rr = r0 + r;
+                const double om = (rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot;
+                const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
+                s += L[B_U + 30 * r + i] * (om * beta);
+            }
+            val = s / Di - L[P_QREF + i];
+        } else val = L[P_MTOP + 30 * (cidx - 1) + i] / Di;
+        L[B_BP + e] = val;
+    }
+    // ---- Cm = Om^-1 + U D^-1 U' (lower)
+    const int ld = 19;
+    for (int e = lane; e < nU * nU; e += 64) {
+        const int r = e / nU, c = e % nU;
+        if (c <= r) {
+            double s = 0.0;
+            for (int i = 0; i < 30; i++) {
+                const double Di = (i < 3) ? P.w_base_pos : (i < 6) ? P.w_base_ang : P.w_joints;
+                s += L[B_U + 30 * r + i] * L[B_U + 30 * c + i] / Di;
+            }
+            if (r == c) { const int rr = r0 + r; s += 1.0 / ((rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot); }
+            L[B_K + ld * r + c] = s;
+        }
+    }
+    WSYNC();
+    for (int e = lane; e < 7 * nU; e += 64) {                      // V' rows: (U bp)'
+        const int cidx = e / nU, r = e % nU;
+        double s = 0.0;
+        for (int i = 0; i < 30; i++) s += L[B_U + 30 * r + i] * L[B_BP + 7 * i + cidx];
+        L[B_K + ld * (nU + cidx) + r] = s;
+    }
+    if (chol_aug(L + B_K, ld, nU, 7)) flags |= LMH_FLAG_NOT_SPD;
+    chol_back(L + B_K, ld, nU, 7);
+    for (int e = lane; e < 210; e += 64) {                         // Y = bp - D^-1 U' t
+        const int i = e / 7, cidx = e % 7;
+        const double Di = (i < 3) ? P.w_base_pos : (i < 6) ? P.w_base_ang : P.w_joints;
+        double s = 0.0;
+        for (int r = 0; r < nU; r++) s += L[B_U + 30 * r + i] * L[B_K + ld * (nU + cidx) + r];
+        L[P_Y + e] = L[B_BP + e] - s / Di;
+    }
+    WSYNC();
+    // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g ; Si = S^-1 via Cholesky with identity rows
+    if (lane < 42) {
+        const int r = lane / 7, cidx = lane % 7;
+        double s = 0.0;
+        for (int i = 0; i < 30; i++) s += L[P_MTOP + 30 * r + i] * L[P_Y + 7 * i + cidx];
+        if (cidx == 0) L[P_D6 + r] = L[P_C + r] - s;
+        else L[B_S + 7 * r + (cidx - 1)] = s;
+    }
+    if (lane >= 42 && lane < 64) { for (int e = lane - 42; e < 36; e += 22) L[B_S + 7 * (6 + e / 6) + e % 6] = (e / 6 == e % 6) ? 1.0 : 0.0; }
+    if (chol_aug(L + B_S, 7, 6, 6)) flags |= LMH_FLAG_NOT_SPD;
+    chol_back(L + B_S, 7, 6, 6);
+    if (lane < 36) L[P_SI + lane] = L[B_S + 7 * (6 + lane / 6) + lane % 6];   // row r = S^-1 e_r (symmetric)
+    WSYNC();
+    // ---- T1 = Jb Si (12x6), W = I + T1 Jb', h = T1 d
+    for (int e = lane; e < 72; e += 64) {
+        const int row = e / 6, c = e % 6;
+        double s = 0.0;
+        for (int k = 0; k < 6; k++) s += jdense(L, row, k) * L[P_SI + 6 * k + c];
+        L[B_T1 + e] = s;
+    }
+    WSYNC();
+    for (int e = lane; e < 156; e += 64) {
+        if (e < 144) {
+            const int r = e / 12, c = e % 12;
+            double s = (r == c) ? P.w_force : 0.0;
+            for (int k = 0; k < 6; k++) s += L[B_T1 + 6 * r + k] * jdense(L, c, k);
+            L[P_W + e] = s;
+        } else {
+            const int r = e - 144;
+            double s = 0.0;
+            for (int k = 0; k < 6; k++) s += L[B_T1 + 6 * r + k] * L[P_D6 + k];
+            L[P_H12 + r] = s;
+        }
+    }
+    WSYNC();
+    // ---- cone QP data: WG = W G, Pm = G' WG + eps I, qv = G' h   (G columns: [n; f] of foot j/16)
+    for (int e = lane; e < 384; e += 64) {
+        const int r = e / 32, j = e % 32, o = 6 * (j / 16);
+        double s = 0.0;
+        for (int k = 0; k < 6; k++) s += L[P_W + 12 * r + o + k] * L[P_GCOL + 6 * j + k];
+        L[C_WG + e] = s;
+    }
+    if (lane < 32) {
+        const int o = 6 * (lane / 16);
+        double s = 0.0;
+        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * lane + k] * L[P_H12 + o + k];
+        L[P_QV + lane] = s;
+    }
+    WSYNC();
+    for (int e = lane; e < 1024; e += 64) {
+        const int i = e / 32, j = e % 32, o = 6 * (i / 16);
+        double s = (i == j) ? P.eps_coeff : 0.0;
+        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * i + k] * L[C_WG + 32 * (o + k) + j];
+        L[C_P + e] = s;
+    }
+    WSYNC();
+    // ---- block principal pivoting on  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
+    unsigned forced = 0u;
+    if (ph == LMH_PHASE_LEFT || ph == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;    // right foot carries no force
+    if (ph == LMH_PHASE_RIGHT || ph == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
+    unsigned F = (P.warm_start ? *Fmask_io : 0xFFFFFFFFu) & ~forced;
+    double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
+    qmax = wave_max(qmax);
+    int ninf = 33, budget = 3, it = 0;
+    int *idx = (int *)(L + C_IDX);
+    const int ldp = 33;
+    for (;;) {
+        it++;
+        const int nF = __popc(F);
+        if (lane < 32 && ((F >> lane) & 1u)) idx[__popc(F & ((1u << lane) - 1u))] = lane;
+        WSYNC();
+        for (int e = lane; e < (nF + 1) * nF; e += 64) {
+            const int a = e / nF, b = e % nF;
+            if (a == nF) L[C_PW + ldp * a + b] = L[P_QV + idx[b]];
+            else if (b <= a) L[C_PW + ldp * a + b] = L[C_P + 32 * idx[a] + idx[b]];
+        }
+        if (nF > 0) {
+            if (chol_aug(L + C_PW, ldp, nF, 1)) flags |= LMH_FLAG_NOT_SPD;
+            chol_back(L + C_PW, ldp, nF, 1);
+        } else WSYNC();
+        double cj = 0.0, lj = 0.0;
+        if (lane < 32) {
+            if ((F >> lane) & 1u) cj = L[C_PW + ldp * nF + __popc(F & ((1u << lane) - 1u))];
+            else {
+                double s = 0.0;
+                for (int b = 0; b < nF; b++) s += L[C_P + 32 * lane + idx[b]] * L[C_PW + ldp * nF + b];
+                lj = s - L[P_QV + lane];
+            }
+        }
+        const double cmax = wave_max(fabs(cj));
+        const double tolc = 1e-9 * (1.0 + cmax), toll = 1e-9 * (1.0 + qmax);
+        const bool isbad = (lane < 32) && !((forced >> lane) & 1u) &&
+                           ((((F >> lane) & 1u) && cj < -tolc) || (!((F >> lane) & 1u) && lj < -toll));
+        const unsigned bad = (unsigned)__ballot(isbad);
+        if (lane < 32) { L[P_CC + lane] = cj; L[P_LAM + lane] = lj; }
+        if (bad == 0u) break;
+        if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
+        const int nb = __popc(bad);
+        if (nb < ninf) { ninf = nb; budget = 3; F ^= bad; }
+        else if (budget > 0) { budget--; F ^= bad; }
+        else F ^= (1u << (31 - __clz(bad)));                       // Murty: flip the highest-index violator only
+        WSYNC();
+    }
+    WSYNC();
+    *Fmask_io = F;
+    *iters_out = it;
+    // ---- recover w = G c, lam = -Si (Jb' w - d), a = -(Y_g + Y_M lam)
+    if (lane < 12) {
+        const int ft = lane / 6, k = lane % 6;
+        double s = 0.0;
+        for (int j = 0; j < 16; j++) s += L[P_GCOL + 6 * (16 * ft + j) + k] * L[P_CC + 16 * ft + j];
+        L[P_W12 + lane] = s;
+    }
+    WSYNC();
+    if (lane < 6) {
+        double s = 0.0;
+        for (int row = 0; row < 12; row++) s += jdense(L, row, lane) * L[P_W12 + row];
+        L[P_LAM6 + lane] = s - L[P_D6 + lane];                     // r = Jb' w - d (temporarily)
+    }
+    WSYNC();
+    double lam = 0.0;
+    if (lane < 6) { for (int k = 0; k < 6; k++) lam += L[P_SI + 6 * lane + k] * L[P_LAM6 + k]; lam = -lam; }
+    WSYNC();
+    if (lane < 6) L[P_LAM6 + lane] = lam;
+    WSYNC();
+    if (lane < 30) {
+        double s = L[P_Y + 7 * lane];
+        for (int k = 0; k < 6; k++) s += L[P_Y + 7 * lane + 1 + k] * L[P_LAM6 + k];
+        L[P_A + lane] = -s;
+    }
+    WSYNC();
+    return flags;
+}
+
+// Controller::WBC tail (controller.cpp:134-153): tau, base acceleration back to the world frame.
+__device__ void phase_outputs(double *L)
+{
+    const int lane = LANE;
+    if (lane < 24) {
+        const int a = lane, st = c_jstart[a], ft = (a < 6) ? 0 : (a < 12) ? 1 : -1;
+        const int nl = (a < 12) ? 6 : (a < 22) ? 5 : 2;
+        double s = 0.0;
+        for (int c = 0; c < 6; c++) s += L[P_MTOP + 30 * c + 6 + a] * L[P_A + c];
+        for (int b = 0; b < nl; b++) s += L[P_HL + 6 * a + b] * L[P_A + 6 + st + b];
+        double jw = 0.0;
+        if (ft >= 0) for (int rr = 0; rr < 6; rr++) jw += L[P_JC + 72 * ft + 12 * rr + 6 + (a - 6 * ft)] * L[P_W12 + 6 * ft + rr];
+        L[P_TAU + a] = s + L[P_C + 6 + a] - jw;
+    }
+    if (lane >= 32 && lane < 38) {                                 // X0 acc = a[0:6]: w = R0 a_ang ; v = R0 (a_lin - B0 w)
+        const int k = lane - 32, r = k % 3;
+        const double *E0 = L + P_X0, *B0 = L + P_X0 + 12, *a = L + P_A;
+        const double w0 = E0[0] * a[0] + E0[1] * a[1] + E0[2] * a[2];
+        const double w1 = E0[3] * a[0] + E0[4] * a[1] + E0[5] * a[2];
+        const double w2 = E0[6] * a[0] + E0[7] * a[1] + E0[8] * a[2];
+        double val;
+        if (k < 3) {                                               // linear part goes first in qdd
+            const double u0 = a[3] - (B0[0] * w0 + B0[1] * w1 + B0[2] * w2);
+            const double u1 = a[4] - (B0[3] * w0 + B0[4] * w1 + B0[5] * w2);
+            const double u2 = a[5] - (B0[6] * w0 + B0[7] * w1 + B0[8] * w2);
+            val = E0[3 * r] * u0 + E0[3 * r + 1] * u1 + E0[3 * r + 2] * u2;
+        } else val = (r == 0) ? w0 : (r == 1) ? w1 : w2;
+        L[P_QDD + k] = val;
+    }
+    if (lane >= 40 && lane < 64) L[P_QDD + 6 + (lane - 40)] = L[P_A + 6 + (lane - 40)];
+    WSYNC();
+}
+
+// one controller evaluation on the state in L[P_Q], L[P_V], L[P_VP] at time t
+__device__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
+{
+    int flags = 0, ph = 0;
+    phase_fk(L);
+    phase_com_x(L);
+    if (dbg) {
+        for (int e = LANE; e < 336; e += 64) dbg[e] = L[A_T + e];
+        for (int e = LANE; e < 252; e += 64) { dbg[336 + e] = L[A_XE + e]; dbg[672 + e] = L[A_XB + e]; }
+        for (int e = LANE; e < 84; e += 64) dbg[588 + e] = L[A_XP + e];
+    }
+    phase_newton_euler(L);
+    phase_crba(L);
+    phase_jacobian(L);
+    flags |= phase_refs(L, P, inst, t, k_out, &ph);
+    flags |= phase_qp(L, P, ph, Fmask, iters_out);
+    phase_outputs(L);
+    if (dbg) {
+        const int lane = LANE;
+        for (int e = lane; e < 30; e += 64) { dbg[924 + e] = L[P_C + e]; dbg[1643 + e] = L[P_QREF + e]; dbg[3181 + e] = L[P_A + e]; }
+        for (int e = lane; e < 6; e += 64) { dbg[954 + e] = L[P_CG + e]; dbg[1464 + e] = L[P_AGPQP + e]; dbg[1673 + e] = L[P_HREF + e]; }
+        for (int e = lane; e < 180; e += 64) { dbg[960 + e] = L[P_MTOP + e]; dbg[1284 + e] = L[P_AG + e]; }
+        for (int e = lane; e < 144; e += 64) { dbg[1140 + e] = L[P_HL + e]; dbg[1482 + e] = L[P_JC + e]; dbg[1937 + e] = L[P_W + e]; }
+        for (int e = lane; e < 12; e += 64) { dbg[1470 + e] = L[P_JPQP + e]; dbg[1679 + e] = L[P_FREF + e]; dbg[2081 + e] = L[P_H12 + e]; }
+        for (int e = lane; e < 9; e += 64) dbg[1626 + e] = L[P_COM + e];
+        for (int e = lane; e < 8; e += 64) dbg[1635 + e] = L[P_MPC + e];
+        for (int e = lane; e < 210; e += 64) dbg[1691 + e] = L[P_Y + e];
+        for (int e = lane; e < 36; e += 64) dbg[1901 + e] = L[P_SI + e];
+        for (int e = lane; e < 1024; e += 64) dbg[2093 + e] = L[C_P + e];
+        for (int e = lane; e < 32; e += 64) { dbg[3117 + e] = L[P_QV + e]; dbg[3149 + e] = L[P_CC + e]; }
+    }
+    // non-finite guard (reference aborts on NaN/Inf, controller.cpp:448-466)
+    double chk = 0.0;
+    if (LANE < 24) chk = L[P_TAU + LANE]; else if (LANE < 36) chk = L[P_W12 + LANE - 24];
+    const bool nf = !(fabs(chk) <= 1.0e300);
+    if (__ballot(nf) != 0ull) flags |= LMH_FLAG_NONFINITE;
+    return flags;
+}
+
+__device__ void load_common(double *L, const LmhDevParams &P, int inst)
+{
+    const double *mo = P.model + (size_t)P.model_stride * inst;
+    for (int e = LANE; e < 393; e += 64) L[P_MODEL + e] = mo[e];
+    for (int e = LANE; e < 192; e += 64) L[P_GCOL + e] = P.gcol[e];
+}
+
+__device__ void store_out(const double *L, double *out)
+{
+    const int lane = LANE;
+    if (lane < 24) out[lane] = L[P_TAU + lane];
+    else if (lane < 36) out[lane] = L[P_W12 + lane - 24];
+    for (int e = lane; e < 30; e += 64) out[36 + e] = L[P_QDD + e];
+}
+
+// ============================================================================ kernels
+// Controller::standStep + WBC for every instance (src/controller.cpp:48-154).
+template <bool DEBUG>
+__global__ void __launch_bounds__(64) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
+{
+    __shared__ double L[LDS_DOUBLES];
+    const int inst = blockIdx.x;
+    if (inst >= P.n_instances) return;
+    double *st = state + (size_t)LMH_STATE_STRIDE * inst;
+    load_common(L, P, inst);
+    for (int e = LANE; e < 91; e += 64) L[P_Q + e] = st[e];        // q | v | v_prev | t
+    WSYNC();
+    const double t = L[P_TIME];
+    unsigned F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
+    F = P.warm_start ? ~F : 0xFFFFFFFFu;                           // status keeps the ACTIVE mask
+    int k = 0, iters = 0;
+    const int flags = controller_eval(L, P, inst, t, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
+    if (LANE < 30) st[60 + LANE] = L[P_V + LANE];                  // Robot::v_ <- dq (controller.cpp:59)
+    if (LANE == 0) {
+        int32_t *s = status + LMH_STATUS_STRIDE * inst;
+        s[0] = k; s[1] = iters; s[2] = flags; s[3] = (int32_t)(~F);
+    }
+}
+
+// Closed loop of apps/offline/main.cpp:66-122: n_ticks x rk4Step(dynamics) with Clock::step.
+__global__ void __launch_bounds__(64) lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *log, int n_ticks)
+{
+    __shared__ double L[LDS_DOUBLES];
+    const int inst = blockIdx.x;
+    if (inst >= P.n_instances) return;
+    const int lane = LANE;
+    double *st = state + (size_t)LMH_STATE_STRIDE * inst;
+    load_common(L, P, inst);
+    // lane i < 60 owns state component i (q | v); v_prev lives in LDS between evaluations
+    double x = (lane < 60) ? st[lane] : 0.0;
+    if (lane < 30) L[P_VP + lane] = st[60 + lane];
+    double t = st[90];
+    unsigned F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
+    F = P.warm_start ? ~F : 0xFFFFFFFFu;
+    int k = 0, iters = 0, flags = 0, itmax = 0;
+    const double dt = P.dt;
+    for (int tick = 0; tick < n_ticks; tick++) {
+        double ksum = 0.0, xs = x;
+        for (int stage = 0; stage < 4; stage++) {
+            const double ts = (stage == 0) ? t : (stage == 3) ? t + dt : t + 0.5 * dt;      // rk4.hpp:12-15
+            WSYNC();
+            if (lane < 60) L[P_Q + lane] = xs;
+            WSYNC();
+            flags |= controller_eval(L, P, inst, ts, &F, &k, &iters, nullptr);
+            itmax = (iters > itmax) ? iters : itmax;
+            // xdot (apps/offline/main.cpp:107-121)
+            double xd = 0.0;
+            if (lane < 60) {
+                if (lane >= 30) xd = L[P_QDD + lane - 30];
+                else if (lane >= 6) xd = L[P_V + lane];
+                else if (lane < 3) {
+                    const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
+                    const double p0 = L[P_Q], p1 = L[P_Q + 1], p2 = L[P_Q + 2];
+                    const double cr = (lane == 0) ? (-w2 * p1 + w1 * p2) : (lane == 1) ? (w2 * p0 - w0 * p2) : (-w1 * p0 + w0 * p1);
+                    xd = L[P_V + lane] + cr;                       // v_classic = v_spatial + w x p
+                } else {
+                    const double sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
+                    const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
+                    const double tp = sp / cp;
+                    xd = (lane == 3) ? (cy / cp) * w0 + (sy / cp) * w1 + 0.0 * w2
+                       : (lane == 4) ? (-sy) * w0 + cy * w1 + 0.0 * w2
+                                     : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
+                }
+            }
+            // Robot::v_ <- dq for the next evaluation
+            WSYNC();
+            if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xs;
+            if (stage == 0) { ksum = xd; xs = x + 0.5 * dt * xd; }
+            else if (stage == 1) { ksum = ksum + 2.0 * xd; xs = x + 0.5 * dt * xd; }
+            else if (stage == 2) { ksum = ksum + 2.0 * xd; xs = x + dt * xd; }
+            else { ksum = ksum + xd; }
+        }
+        x = x + (dt / 6.0) * ksum;                                  // rk4.hpp:17
+        if (log) {
+            double *lg = log + ((size_t)tick * P.n_instances + inst) * 36;
+            if (lane < 24) lg[lane] = L[P_TAU + lane]; else if (lane < 36) lg[lane] = L[P_W12 + lane - 24];
+        }
+        t += dt;                                                    // Clock::step, Clock.hpp:11
+    }
+    WSYNC();
+    store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
+    if (lane < 60) st[lane] = x;
+    if (lane < 30) st[60 + lane] = L[P_VP + lane];
+    if (lane == 0) {
+        st[90] = t;
+        int32_t *s = status + LMH_STATUS_STRIDE * inst;
+        s[0] = k; s[1] = itmax; s[2] = flags; s[3] = (int32_t)(~F);
+    }
+}
+
+// Robot::Robot model preparation (Robot.cpp:14-22) + Dynamics::spatialInertiaMatrix pieces
+// (Dynamics.cpp:4-13): raw [28][13] -> device model record.
+__global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double *model, int n_models)
+{
+    __shared__ double L[LDS_DOUBLES];
+    const int mi = blockIdx.x;
+    if (mi >= n_models) return;
+    const int lane = LANE;
+    const double *rw = raw + (size_t)mi * 28 * LMH_LINK_STRIDE;
+    for (int e = lane; e < 30; e += 64) L[P_Q + e] = 0.0;          // FK at q = 0
+    WSYNC();
+    phase_fk(L);
+    double mloc = 0.0;
+    if (lane < 28) {
+        const double *T = L + A_T + 12 * lane, *lk = rw + LMH_LINK_STRIDE * lane;
+        const double m = lk[0];
+        double c[3], I1[9], I2[9];
+        for (int a = 0; a < 3; a++) c[a] = T[a] * lk[1] + T[4 + a] * lk[2] + T[8 + a] * lk[3];           // Rj' com
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) I1[3 * a + b] = T[a] * lk[4 + b] + T[4 + a] * lk[7 + b] + T[8 + a] * lk[10 + b];   // Rj' I
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) I2[3 * a + b] = I1[3 * a] * T[b] + I1[3 * a + 1] * T[4 + b] + I1[3 * a + 2] * T[8 + b]; // (Rj' I) Rj
+        // cc = [c]x [c]x ; Ibar = I - m cc
+        const double cm[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+        double *mo = model + (size_t)mi * LMH_MODEL_STRIDE + LMH_BODY_STRIDE * lane;
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                const double cc = cm[3 * a] * cm[b] + cm[3 * a + 1] * cm[3 + b] + cm[3 * a + 2] * cm[6 + b];
+                mo[3 * a + b] = I2[3 * a + b] - (m * cc);
+            }
+        for (int a = 0; a < 3; a++) mo[9 + a] = m * c[a];
+        mo[12] = m; mo[13] = 0.0;
+        mloc = m;
+    }
+    // mass_ += links_[i].mass in frame order (Robot.cpp:21)
+    if (lane == 0) {
+        double s = 0.0;
+        for (int i = 0; i < 28; i++) s += rw[LMH_LINK_STRIDE * i];
+        model[(size_t)mi * LMH_MODEL_STRIDE + 392] = s;
+    }
+    (void)mloc;
+}
+
+
+// ============================================================================ inverse kinematics
+// Kinematics::compute (src/invKinematics.cpp:27-52): Newton iteration on the operational state
+// [feet pose(12) | arm+head joints(12) | base rpy(3) | CoM(3)], Jacobian as jacInvKinematics
+// (:151-204) builds it, linear solve by Gaussian elimination with partial pivoting (the
+// reference uses colPivHouseholderQr on the same square system).  One wave per instance.
+enum { IK_J = LDS_DOUBLES, IK_E = LDS_DOUBLES + 930, IK_Q = LDS_DOUBLES + 960, IK_OM = LDS_DOUBLES + 1008, IK_LDS = LDS_DOUBLES + 1040 };
+
+__device__ void rot_to_euler_dev(const double *T /*3x4*/, double *eta)   // invKinematics.cpp:256-267, newR = R * Rf_q0
+{
+    double nR[9];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) nR[3 * a + b] = T[4 * a] * c_rdes[b] + T[4 * a + 1] * c_rdes[3 + b] + T[4 * a + 2] * c_rdes[6 + b];
+    eta[2] = atan2(nR[3], nR[0]);
+    eta[1] = atan2(-nR[6], cos(eta[2]) * nR[0] + sin(eta[2]) * nR[3]);
+    eta[0] = atan2(sin(eta[2]) * nR[2] - cos(eta[2]) * nR[5], -sin(eta[2]) * nR[1] + cos(eta[2]) * nR[4]);
+}
+__device__ void omega_mat(const double *eta, double *Om)                 // generalizedFunctions.cpp:43-50
+{
+    Om[0] = cos(eta[2]) / cos(eta[1]); Om[1] = sin(eta[2]) / cos(eta[1]); Om[2] = 0;
+    Om[3] = -sin(eta[2]); Om[4] = cos(eta[2]); Om[5] = 0;
+    Om[6] = cos(eta[2]) * tan(eta[1]); Om[7] = sin(eta[2]) * tan(eta[1]); Om[8] = 1;
+}
+__device__ void inv3_dev(const double *A, double *Ai)
+{
+    const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    Ai[0] = (A[4] * A[8] - A[5] * A[7]) / det; Ai[1] = (A[2] * A[7] - A[1] * A[8]) / det; Ai[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+    Ai[3] = (A[5] * A[6] - A[3] * A[8]) / det; Ai[4] = (A[0] * A[8] - A[2] * A[6]) / det; Ai[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+    Ai[6] = (A[3] * A[7] - A[4] * A[6]) / det; Ai[7] = (A[1] * A[6] - A[0] * A[7]) / det; Ai[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+}
+
+__global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio, const double *target, int32_t *iters_out)
+{
+    __shared__ double L[IK_LDS];
+    const int inst = blockIdx.x;
+    if (inst >= P.n_instances) return;
+    const int lane = LANE;
+    load_common(L, P, inst);
+    if (lane < 30) L[P_Q + lane] = qio[30 * (size_t)inst + lane];
+    WSYNC();
+    // desiredOperationalState (:11-25): feet pose, CURRENT arm/head joints, zero base attitude, CoM target
+    double des = 0.0;
+    if (lane < 12) des = target[lane];
+    else if (lane < 24) des = L[P_Q + 18 + (lane - 12)];
+    else if (lane < 27) des = 0.0;
+    else if (lane < 30) des = target[12 + (lane - 27)];
+    const double mass = L[P_MODEL + 392];
+    int iter = 0;
+    for (;;) {
+        phase_fk(L);
+        phase_com_x(L);
+        phase_jacobian(L);
+        // operationalState (:54-70)
+        double Qv = 0.0;
+        if (lane < 12) {
+            const int ft = lane / 6, k = lane % 6;
+            const double *T = L + P_TB + 12 * (1 + ft);
+            if (k < 3) Qv = T[4 * k + 3];
+            else { double eta[3]; rot_to_euler_dev(T, eta); Qv = eta[k - 3]; }
+        } else if (lane < 24) Qv = L[P_Q + 18 + (lane - 12)];
+        else if (lane < 27) Qv = L[P_Q + 3 + (lane - 24)];
+        else if (lane < 30) Qv = L[P_COM + (lane - 27)];
+        const double e = (lane < 30) ? des - Qv : 0.0;
+        const double crit = wave_max(fabs(e));
+        if (!(crit > 1e-10) || iter >= 200) break;
+        if (lane < 30) L[IK_E + lane] = e;
+        // ---- jacInvKinematics (:151-204)
+        if (lane == 0) {
+            double Om[9], Oi[9];
+            omega_mat(L + P_Q + 3, Om); inv3_dev(Om, Oi);
+            for (int k = 0; k < 9; k++) L[IK_OM + k] = Oi[k];
+            for (int ft = 0; ft < 2; ft++) {
+                double eta[3], Of[9];
+                rot_to_euler_dev(L + P_TB + 12 * (1 + ft), eta); omega_mat(eta, Of);
+                for (int k = 0; k < 9; k++) L[IK_OM + 9 + 9 * ft + k] = Of[k];
+            }
+        }
+        WSYNC();
+        for (int el = lane; el < 900; el += 64) {
+            const int r = el / 30, c = el % 30;
+            double val = 0.0;
+            if (r < 12) {
+                // rows: per foot [lin(3); ang(3)] <- source rows [ang; lin]; base columns [lin | ang] <- source [ang | lin]
+                const int ft = r / 6, rk = r % 6, srow = 6 * ft + ((rk < 3) ? rk + 3 : rk - 3);
+                if (c >= 6) val = jdense(L, srow, c);
+                else if (c < 3) val = jdense(L, srow, c + 3);
+                else {
+                    // block(.,3,3,3) * Omega^-1 on source columns 0..2 (angular velocity of the base)
+                    double b0 = 0.0;
+                    for (int k = 0; k < 3; k++) b0 += jdense(L, srow, k) * L[IK_OM + 3 * k + (c - 3)];
+                    val = b0;
+                    if (rk >= 3) {                                 // OmegaFoot * block (angular rows only, :191-197)
+                        double acc = 0.0;
+                        for (int m2 = 0; m2 < 3; m2++) {
+                            const int srow2 = 6 * ft + m2;         // source angular rows
+                            double bm = 0.0;
+                            for (int k = 0; k < 3; k++) bm += jdense(L, srow2, k) * L[IK_OM + 3 * k + (c - 3)];
+                            acc += L[IK_OM + 9 + 9 * ft + 3 * (rk - 3) + m2] * bm;
+                        }
+                        val = acc;
+                    }
+                }
+            } else if (r < 24) val = (c == 18 + (r - 12)) ? 1.0 : 0.0;
+            else if (r < 27) val = (c == 3 + (r - 24)) ? 1.0 : 0.0;
+            L[IK_J + 31 * r + c] = val;
+        }
+        WSYNC();
+        // comJacobian (:206-244), rows 27..29: one lane per column
+        if (lane < 30) {
+            double j0 = 0, j1 = 0, j2 = 0;
+            for (int i = 0; i < 27; i++) {
+                const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
+                const double m = mo[12];
+                if (m == 0.0) continue;
+                const double *T = L + A_T + 12 * i;
+                const double c0 = mo[9] / m, c1 = mo[10] / m, c2 = mo[11] / m;
+                const double pc0 = T[0] * c0 + T[1] * c1 + T[2] * c2 + T[3];
+                const double pc1 = T[4] * c0 + T[5] * c1 + T[6] * c2 + T[7];
+                const double pc2 = T[8] * c0 + T[9] * c1 + T[10] * c2 + T[11];
+                double x0 = 0, x1 = 0, x2 = 0;
+                if (lane < 3) { x0 = (lane == 0); x1 = (lane == 1); x2 = (lane == 2); }
+                else if (lane < 6) {                                // crossMatrix(pBase - pCom) column (lane-3)
+                    const double d0 = L[A_T + 3] - pc0, d1 = L[A_T + 7] - pc1, d2 = L[A_T + 11] - pc2;
+                    if (lane == 3) { x0 = 0; x1 = d2; x2 = -d1; }
+                    else if (lane == 4) { x0 = -d2; x1 = 0; x2 = d0; }
+                    else { x0 = d1; x1 = -d0; x2 = 0; }
+                } else {
+                    // joint (lane-6) contributes if its frame is on the path from frame i to the base
+                    const int jf = c_jframe[lane - 6];
+                    int j = i; bool on = false;
+                    while (j != 0) { if (j == jf) { on = true; break; } j = c_parent[j]; }
+                    if (on) {
+                        const double *Tj = L + A_T + 12 * jf;
+                        const double z0 = Tj[2], z1 = Tj[6], z2 = Tj[10];
+                        const double d0 = pc0 - Tj[3], d1 = pc1 - Tj[7], d2 = pc2 - Tj[11];
+                        x0 = z1 * d2 - z2 * d1; x1 = z2 * d0 - z0 * d2; x2 = z0 * d1 - z1 * d0;
+                    }
+                }
+                j0 = j0 + m * x0; j1 = j1 + m * x1; j2 = j2 + m * x2;
+            }
+            L[IK_J + 31 * 27 + lane] = j0 / mass; L[IK_J + 31 * 28 + lane] = j1 / mass; L[IK_J + 31 * 29 + lane] = j2 / mass;
+        }
+        WSYNC();
+        if (lane < 9) {                                             // J.block(0,3,3,3) *= Omega^-1 on the CoM rows
+            const int r = lane / 3, c = lane % 3;
+            double s = 0.0;
+            for (int k = 0; k < 3; k++) s += L[IK_J + 31 * (27 + r) + 3 + k] * L[IK_OM + 3 * k + c];
+            L[IK_Q + lane] = s;
+        }
+        WSYNC();
+        if (lane < 9) L[IK_J + 31 * (27 + lane / 3) + 3 + lane % 3] = L[IK_Q + lane];
+        if (lane < 30) L[IK_J + 31 * lane + 30] = L[IK_E + lane];   // augmented rhs
+        WSYNC();
+        // ---- Gaussian elimination with partial pivoting on [J | e] (30 x 31)
+        for (int c = 0; c < 30; c++) {
+            double best = (lane >= c && lane < 30) ? fabs(L[IK_J + 31 * lane + c]) : -1.0;
+            int bi = lane;
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (bi != c && lane < 31) { const double t = L[IK_J + 31 * c + lane]; L[IK_J + 31 * c + lane] = L[IK_J + 31 * bi + lane]; L[IK_J + 31 * bi + lane] = t; }
+            WSYNC();
+            const double piv = L[IK_J + 31 * c + c];
+            const int nr = 29 - c, nc = 30 - c;                     // rows below, columns right (incl. rhs)
+            for (int el = lane; el < nr * nc; el += 64) {
+                const int r = c + 1 + el / nc, cc = c + 1 + el % nc;
+                L[IK_J + 31 * r + cc] -= (L[IK_J + 31 * r + c] / piv) * L[IK_J + 31 * c + cc];
+            }
+            WSYNC();
+        }
+        for (int r = 29; r >= 0; r--) {                             // back substitution
+            const double xr = L[IK_J + 31 * r + 30] / L[IK_J + 31 * r + r];
+            WSYNC();
+            if (lane < r) L[IK_J + 31 * lane + 30] -= L[IK_J + 31 * lane + r] * xr;
+            if (lane == 0) L[IK_Q + 16 + r] = xr;
+            WSYNC();
+        }
+        if (lane < 30) L[P_Q + lane] += L[IK_Q + 16 + lane];        // q += dq
+        WSYNC();
+        iter++;
+    }
+    if (lane < 30) qio[30 * (size_t)inst + lane] = L[P_Q + lane];
+    if (lane == 0 && iters_out) iters_out[inst] = iter;
+}
+
+extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const double *target, int32_t *iters, hipStream_t s)
+{
+    hipLaunchKernelGGL(lmh_ik_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, target, iters);
+}
+
+extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s)
+{
+    if (debug) hipLaunchKernelGGL(lmh_eval_kernel<true>, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
+    else hipLaunchKernelGGL(lmh_eval_kernel<false>, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
+}
+extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
+{
+    hipLaunchKernelGGL(lmh_rollout_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, log, n_ticks);
+}
+extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, hipStream_t s)
+{
+    hipLaunchKernelGGL(lmh_model_kernel, dim3(n_models), dim3(64), 0, s, raw, model, n_models);
+}

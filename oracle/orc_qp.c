@@ -191,7 +191,9 @@ int orc_qp_solve(int n, const double *H, const double *g, int m, const double *A
             if (zz > DBL_EPSILON * DBL_EPSILON && zn > 0.0) t2 = -sp / zn;
             if (ip < ne) { t1 = ORC_INFTY; l = -1; if (zn > 0.0) t2 = -sp / zn; }   /* equality: signed full step */
             double t = (t1 < t2) ? t1 : t2;
+            if (!(t == t)) { status = 5; goto done; }              /* NaN in the data */
             if (t >= ORC_INFTY) { status = 1; goto done; }         /* infeasible */
+            if (t != t2 && l < 0) { status = 5; goto done; }
             if (t2 >= ORC_INFTY) {
                 /* dual step only */
                 for (int k = 0; k < w.q; k++) u[k] -= t * w.r[k];
