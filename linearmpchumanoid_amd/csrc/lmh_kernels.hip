@@ -723,6 +723,128 @@ __device__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, 
     return flags;
 }
 
+
+// Solve P_FF z_F = qv_F on the free set F (compact Cholesky in C_PW).  Returns z_j for lane j in F
+// (0 otherwise) and, for lanes not in F, the multiplier lam_j = (P z - qv)_j.  idx[] = compact -> index.
+__device__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
+{
+    const int lane = LANE;
+    int *idx = (int *)(L + C_IDX);
+    const int ldp = 33;
+    int bad = 0;
+    const int nF = __popc(F);
+    WSYNC();
+    if (lane < 32 && ((F >> lane) & 1u)) idx[__popc(F & ((1u << lane) - 1u))] = lane;
+    WSYNC();
+    for (int e = lane; e < (nF + 1) * nF; e += 64) {
+        const int a = e / nF, b = e % nF;
+        if (a == nF) L[C_PW + ldp * a + b] = L[P_QV + idx[b]];
+        else if (b <= a) L[C_PW + ldp * a + b] = L[C_P + 32 * idx[a] + idx[b]];
+    }
+    if (nF > 0) {
+        bad = chol_aug(L + C_PW, ldp, nF, 1);
+        chol_back(L + C_PW, ldp, nF, 1);
+    } else WSYNC();
+    double zj = 0.0, lj = 0.0;
+    if (lane < 32) {
+        if ((F >> lane) & 1u) zj = L[C_PW + ldp * nF + __popc(F & ((1u << lane) - 1u))];
+        else {
+            double s = 0.0;
+            for (int b = 0; b < nF; b++) s += L[C_P + 32 * lane + idx[b]] * L[C_PW + ldp * nF + b];
+            lj = s - L[P_QV + lane];
+        }
+    }
+    *z_out = zj; *lam_out = lj;
+    return bad;
+}
+
+// min 1/2 c'Pc - qv'c  s.t. c >= 0, c_j = 0 for j in `forced`.  P = G'WG + eps I is SPD, so the
+// minimiser is unique.  Fast path: block principal pivoting from the incoming free set (one solve when
+// the active set did not change, typically <= 8 from a cold start).  If that has not settled after
+// BPP_MAX rounds, a Lawson-Hanson active-set pass from the empty set finishes (monotone, finite).
+#define BPP_MAX 10
+__device__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters)
+{
+    const int lane = LANE;
+    int flags = 0, it = 0;
+    unsigned F = *F_io & ~forced;
+    double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
+    qmax = wave_max(qmax);
+    const double toll = 1e-12 * (1.0 + qmax);                    // ~100x the round-off of (P c - q)
+    const bool mine = (lane < 32) && !((forced >> lane) & 1u);
+    int ninf = 33, budget = 3;
+    bool done = false;
+    double cj = 0.0, lj = 0.0;
+    while (it < BPP_MAX) {
+        it++;
+        if (solve_free_set(L, F, &cj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+        const double cmax = wave_max(fabs(cj));
+        const double tolc = 1e-10 * (1.0 + cmax);
+        const bool isbad = mine && ((((F >> lane) & 1u) && cj < -tolc) || (!((F >> lane) & 1u) && lj < -toll));
+        const unsigned bad = (unsigned)__ballot(isbad);
+        if (bad == 0u) { done = true; break; }
+        const int nb = __popc(bad);
+        if (nb < ninf) { ninf = nb; budget = 3; F ^= bad; }
+        else if (budget > 0) { budget--; F ^= bad; }
+        else F ^= (1u << (31 - __clz((int)bad)));                  // Murty: flip the highest-index violator only
+    }
+    if (!done) {
+        // ---- Lawson-Hanson from the empty free set (c = 0 is feasible)
+        F = 0u; cj = 0.0;
+        for (;;) {
+            // w = qv - P c on the active set; pick the most violated multiplier
+            int *idx = (int *)(L + C_IDX);
+            WSYNC();
+            if (lane < 32) L[P_CC + lane] = cj;
+            WSYNC();
+            double wj = -1.0e300;
+            if (mine && !((F >> lane) & 1u)) {
+                double s = 0.0;
+                for (int b = 0; b < 32; b++) s += L[C_P + 32 * lane + b] * L[P_CC + b];
+                wj = L[P_QV + lane] - s;
+            }
+            double best = wj; int bi = lane;
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (!(best > toll)) break;                             // dual feasible: optimal
+            if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
+            F |= (1u << bi);
+            for (;;) {                                             // inner loop: keep c >= 0
+                it++;
+                double zj, dummy;
+                if (solve_free_set(L, F, &zj, &dummy)) flags |= LMH_FLAG_NOT_SPD;
+                const bool inF = (lane < 32) && ((F >> lane) & 1u);
+                const bool neg = inF && !(zj > 0.0);
+                const unsigned negm = (unsigned)__ballot(neg);
+                if (negm == 0u) { cj = inF ? zj : 0.0; break; }
+                double al = neg ? ((cj - zj > 0.0) ? cj / (cj - zj) : 0.0) : 1.0e300;
+                double amin = al; int ai = lane;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ob = __shfl_xor(amin, o, 64); const int oi = __shfl_xor(ai, o, 64);
+                    if (ob < amin || (ob == amin && oi < ai)) { amin = ob; ai = oi; }
+                }
+                if (inF) cj = cj + amin * (zj - cj);
+                const bool drop = neg && (cj <= 0.0 || lane == ai);
+                const unsigned dm = (unsigned)__ballot(drop);
+                if (drop) cj = 0.0;
+                F &= ~dm;
+                if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
+            }
+            if (flags & LMH_FLAG_QP_MAXITER) break;
+            (void)idx;
+        }
+        lj = 0.0;
+    }
+    WSYNC();
+    if (lane < 32) { L[P_CC + lane] = ((F >> lane) & 1u) ? cj : 0.0; L[P_LAM + lane] = lj; }
+    WSYNC();
+    *F_io = F;
+    *iters = it;
+    return flags;
+}
+
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
 __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out)
 {
@@ -840,53 +962,13 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
         L[C_P + e] = s;
     }
     WSYNC();
-    // ---- block principal pivoting on  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
+    // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
     unsigned forced = 0u;
     if (ph == LMH_PHASE_LEFT || ph == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;    // right foot carries no force
     if (ph == LMH_PHASE_RIGHT || ph == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
     unsigned F = (P.warm_start ? *Fmask_io : 0xFFFFFFFFu) & ~forced;
-    double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
-    qmax = wave_max(qmax);
-    int ninf = 33, budget = 3, it = 0;
-    int *idx = (int *)(L + C_IDX);
-    const int ldp = 33;
-    for (;;) {
-        it++;
-        const int nF = __popc(F);
-        if (lane < 32 && ((F >> lane) & 1u)) idx[__popc(F & ((1u << lane) - 1u))] = lane;
-        WSYNC();
-        for (int e = lane; e < (nF + 1) * nF; e += 64) {
-            const int a = e / nF, b = e % nF;
-            if (a == nF) L[C_PW + ldp * a + b] = L[P_QV + idx[b]];
-            else if (b <= a) L[C_PW + ldp * a + b] = L[C_P + 32 * idx[a] + idx[b]];
-        }
-        if (nF > 0) {
-            if (chol_aug(L + C_PW, ldp, nF, 1)) flags |= LMH_FLAG_NOT_SPD;
-            chol_back(L + C_PW, ldp, nF, 1);
-        } else WSYNC();
-        double cj = 0.0, lj = 0.0;
-        if (lane < 32) {
-            if ((F >> lane) & 1u) cj = L[C_PW + ldp * nF + __popc(F & ((1u << lane) - 1u))];
-            else {
-                double s = 0.0;
-                for (int b = 0; b < nF; b++) s += L[C_P + 32 * lane + idx[b]] * L[C_PW + ldp * nF + b];
-                lj = s - L[P_QV + lane];
-            }
-        }
-        const double cmax = wave_max(fabs(cj));
-        const double tolc = 1e-9 * (1.0 + cmax), toll = 1e-9 * (1.0 + qmax);
-        const bool isbad = (lane < 32) && !((forced >> lane) & 1u) &&
-                           ((((F >> lane) & 1u) && cj < -tolc) || (!((F >> lane) & 1u) && lj < -toll));
-        const unsigned bad = (unsigned)__ballot(isbad);
-        if (lane < 32) { L[P_CC + lane] = cj; L[P_LAM + lane] = lj; }
-        if (bad == 0u) break;
-        if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
-        const int nb = __popc(bad);
-        if (nb < ninf) { ninf = nb; budget = 3; F ^= bad; }
-        else if (budget > 0) { budget--; F ^= bad; }
-        else F ^= (1u << (31 - __clz(bad)));                       // Murty: flip the highest-index violator only
-        WSYNC();
-    }
+    int it = 0;
+    flags |= cone_qp(L, P, forced, &F, &it);
     WSYNC();
     *Fmask_io = F;
     *iters_out = it;

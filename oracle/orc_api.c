@@ -244,3 +244,12 @@ double orc_batch_rollout(int B, double *states, double *prev_v, double *out, dou
     free(th); free(args);
     return (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
 }
+
+/* re-initialise the LIPM with a caller-chosen height (Mpc3dLip ctor argument, main.cpp:39) */
+void orc_sys_set_zcom(void *h, double zcom)
+{
+    orc_box *b = (orc_box *)h;
+    int faithful = b->sys.mpc.faithful_rebuild;
+    orc_mpc_init(&b->sys.mpc, b->sys.mpc.dt, b->sys.mpc.timeHorizon, zcom);
+    b->sys.mpc.faithful_rebuild = faithful;
+}

@@ -36,6 +36,7 @@ def lib():
         _lib.orc_sys_mass.restype = C.c_double
         _lib.orc_sys_zcom.restype = C.c_double
         _lib.orc_batch_rollout.restype = C.c_double
+        _lib.orc_sys_set_zcom.argtypes = [C.c_void_p, C.c_double]
         for name in ("orc_sys_destroy", "orc_sys_mass", "orc_sys_horizon", "orc_sys_zcom", "orc_sys_nzmp"):
             getattr(_lib, name).argtypes = [C.c_void_p]
     return _lib
@@ -106,6 +107,9 @@ class Oracle:
     def set_q(self, q):
         q = np.ascontiguousarray(q, dtype=np.float64)
         lib().orc_sys_set_q(self._h, _p(q))
+
+    def set_zcom(self, z):
+        lib().orc_sys_set_zcom(self._h, C.c_double(z))
 
     def set_wbc_calls(self, n, faithful=False):
         lib().orc_sys_set_wbc_calls(self._h, int(n), int(faithful))

@@ -1,0 +1,278 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties of the problem.
+
+Tolerances (north_star): 1e-6 relative on torques / forces (absolute floor 1e-9 * max|.|),
+bit-exact on the preview index k.  fp64 throughout.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL_REL, dense_terms_from_debug, oracle_system, perturbed_velocities, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_controller(B, dt, th, zcom, **kw):
+    from linearmpchumanoid_amd.controller import BatchedController, default_config
+    ctl = BatchedController(B, default_config(dt=dt, time_horizon=th, z_com=zcom, **kw))
+    return ctl
+
+
+@pytest.fixture(scope="module")
+def cfg2():
+    """BASELINE config 2 constants: dt = 1 ms, N = 16."""
+    o = oracle_system(1e-3, 0.016)
+    return dict(dt=1e-3, th=0.016, zcom=o.zcom, q0=o.robot()["q"].copy())
+
+
+def test_extension_loaded_is_the_hip_library():
+    from linearmpchumanoid_amd import capi
+    assert os.path.exists(capi.SO_PATH)
+    assert capi.lib().lmh_device_count() >= 1
+
+
+def test_model_setup_matches_oracle(cfg2):
+    """Robot ctor re-expression + total mass (Robot.cpp:14-22) computed on the GPU."""
+    ctl = make_controller(2, cfg2["dt"], cfg2["th"], cfg2["zcom"])
+    o = oracle_system(cfg2["dt"], cfg2["th"])
+    assert abs(ctl.mass()[0] - o.mass) < 1e-15
+    assert rel_err(ctl.mpc_gain(), o.gain_row()) < 1e-12
+
+
+def test_stage_parity_single_evaluation(cfg2):
+    """Unit parity per stage: T, X, C, Cg, M, AG, AGpqp, Jpqp, J, CoM, MPC u0, PD refs, QP x, tau, f, qdd."""
+    from linearmpchumanoid_amd.controller import unpack_debug
+    B = 24
+    v = perturbed_velocities(B); v[0] = 0
+    vprev = perturbed_velocities(B, seed=555)
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=0)
+    ctl.set_refs_stance(2.0, 2)
+    st = ctl.new_state(cfg2["q0"], v, t=0.0, v_prev=vprev)
+    out, status, dbg = ctl.stand_step(st, debug=True)
+    torch.cuda.synchronize()
+    out, status, dbg, stn = out.cpu().numpy(), status.cpu().numpy(), dbg.cpu().numpy(), st.cpu().numpy()
+    mask_mismatch = 0
+    for i in range(B):
+        o = oracle_system(cfg2["dt"], cfg2["th"])
+        o.set_prev_velocity(vprev[i])
+        e = o.eval(cfg2["q0"], v[i], 0.0)
+        t, qp, rb = o.terms(), o.qp(), o.robot()
+        d = unpack_debug(dbg[i]); dd = dense_terms_from_debug(d)
+        tight = dict(T=(dd["T"], t["T"]), X=(dd["X"], t["X"]), C=(d["C"], t["C"]), M=(dd["M"], t["M"]), AG=(d["AG"], t["AG"]),
+                     J=(dd["J"], t["J"]), CoM=(d["CoM"], rb["CoM"]), qref=(d["qppRef"], qp["qppRef"]), href=(d["hGpRef"], qp["hGpRef"]))
+        for name, (a, b) in tight.items():
+            assert rel_err(a, b) < 1e-11, (i, name, rel_err(a, b))
+        # velocity-product terms are differences of O(50) quantities: compare on that scale
+        assert np.abs(d["Cg6"] - t["Cg"][:6]).max() < 1e-11 * np.abs(t["C"]).max()
+        assert np.abs(d["AGpqp"] - t["AGpqp"]).max() < 1e-11 * np.abs(t["C"]).max()
+        assert np.abs(d["Jpqp"] - t["Jpqp"]).max() < 1e-11 * max(1.0, np.abs(t["Jpqp"]).max())
+        assert np.abs(d["footAccRef"] - qp["footAccRef"]).max() < 1e-10 * max(1.0, np.abs(qp["footAccRef"]).max())
+        assert np.abs(d["mpc"][:2] - qp["u0"]).max() < 1e-11 * max(1.0, np.abs(qp["u0"]).max())
+        assert rel_err(d["a"], qp["x"][:30]) < 1e-8
+        assert rel_err(out[i, :24], e["tau"]) < TOL_REL and rel_err(out[i, 24:36], e["f"]) < TOL_REL
+        assert rel_err(out[i, 36:66], e["qpp"]) < TOL_REL
+        assert status[i, 0] == e["k"] and status[i, 2] == 0
+        mask_mismatch += int((int(status[i, 3]) & 0xFFFFFFFF) != e["active_mask"])
+        assert np.array_equal(stn[i, 60:90], v[i])           # Robot::v_ <- dq
+    assert mask_mismatch <= B // 6                           # degenerate (c_j == 0) ties may differ
+
+
+def test_golden_eval_vectors_reference_literals():
+    """Committed fixtures at the reference's own dt = 0.01 / N = 50 (apps/offline literals)."""
+    g = np.load(os.path.join(GOLD, "eval_vectors.npz"))
+    B = g["q"].shape[0]
+    ctl = make_controller(B, float(g["dt"]), float(g["time_horizon"]), float(g["z_com"]), warm_start=0)
+    ctl.set_refs_stance(5.0, 2)
+    st = ctl.new_state(g["q"], g["v"], t=float(g["t"]), v_prev=g["v_prev"])
+    out, status = ctl.stand_step(st)
+    torch.cuda.synchronize()
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    for i in range(B):
+        assert status[i, 0] == int(g["k"][i]) and status[i, 2] == 0
+        assert rel_err(out[i, :24], g["tau"][i]) < TOL_REL
+        assert rel_err(out[i, 24:36], g["f"][i]) < TOL_REL
+        assert rel_err(out[i, 36:66], g["qpp"][i]) < TOL_REL
+
+
+def test_rollout_parity_config2_fixture():
+    """RK4 closed loop (stale Robot::v_, float-accumulated clock) vs the committed oracle rollout."""
+    g = np.load(os.path.join(GOLD, "rollout_config2.npz"))
+    B, nt = g["v"].shape[0], g["log"].shape[1]
+    for warm in (0, 1):
+        ctl = make_controller(B, float(g["dt"]), float(g["time_horizon"]), float(g["z_com"]), warm_start=warm)
+        ctl.set_refs_stance(2.0, 2)
+        st = ctl.new_state(g["q0"], g["v"], t=0.0)
+        out, status, log = ctl.rollout(st, nt, log=True)
+        torch.cuda.synchronize()
+        stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
+        for i in range(B):
+            assert status[i, 0] == int(g["k"][i][-1]) and status[i, 2] == 0
+            assert np.abs(stn[i, :60] - g["state"][i]).max() < 1e-8 * max(1.0, np.abs(g["state"][i]).max())
+            for tk in range(nt):
+                assert rel_err(log[tk, i, :24], g["log"][i, tk, :24]) < TOL_REL, (warm, i, tk)
+                assert rel_err(log[tk, i, 24:], g["log"][i, tk, 24:]) < TOL_REL, (warm, i, tk)
+            assert abs(stn[i, 90] - nt * float(g["dt"])) < 1e-12
+
+
+def test_offline_app_trace_parity():
+    """apps/offline workload (dt = 0.01, N = 50, 120 of the 500 ticks): state, k, CoM-x trace."""
+    g = np.load(os.path.join(GOLD, "offline_trace.npz"))
+    import json
+    ik = json.load(open(os.path.join(GOLD, "ik_posture.json")))
+    ctl = make_controller(1, 0.01, 0.5, ik["z_com"], warm_start=0)
+    ctl.set_refs_stance(5.0, 2)
+    st = ctl.new_state(np.array(ik["q"]), np.zeros(30), t=0.0)
+    o = oracle_system(0.01, 0.5, sim_time=5.0)
+    r = o.rollout(np.concatenate([np.array(ik["q"]), np.zeros(30)]), 0.0, 120, log=True)
+    out, status, log = ctl.rollout(st, 120, log=True)
+    torch.cuda.synchronize()
+    assert int(status.cpu().numpy()[0, 0]) == int(g["k"][119])
+    assert np.abs(st.cpu().numpy()[0, :60] - r["state"]).max() < 1e-9
+    assert rel_err(log.cpu().numpy()[-1, 0], r["log"][-1]) < TOL_REL
+
+
+def test_eval_then_eval_keeps_reference_state_semantics(cfg2):
+    """Two consecutive standStep calls: the second sees the first call's dq as Robot::v_."""
+    v = perturbed_velocities(4, seed=77)
+    ctl = make_controller(4, cfg2["dt"], cfg2["th"], cfg2["zcom"])
+    ctl.set_refs_stance(2.0, 2)
+    st = ctl.new_state(cfg2["q0"], v, t=0.0)
+    ctl.stand_step(st)
+    st[:, 30:60] *= 0.5
+    out, status = ctl.stand_step(st)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in range(4):
+        o = oracle_system(cfg2["dt"], cfg2["th"])
+        o.eval(cfg2["q0"], v[i], 0.0)
+        e = o.eval(cfg2["q0"], 0.5 * v[i], 0.0)
+        assert rel_err(out[i, :24], e["tau"]) < TOL_REL and rel_err(out[i, 24:36], e["f"]) < TOL_REL
+
+
+def test_support_phases_and_flight(cfg2):
+    """Edge cases: single support (one foot's wrench exactly zero), flight (no contact force at all)."""
+    B = 6
+    v = perturbed_velocities(B, seed=31) * 0.3
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=0)
+    n = 2500
+    for ph, dead in ((1, slice(30, 36)), (2, slice(24, 30)), (3, slice(24, 36))):
+        ctl.set_refs(np.zeros(n), np.zeros(n), np.full(n, ph, dtype=np.uint8))
+        st = ctl.new_state(cfg2["q0"], v, t=0.0)
+        out, status = ctl.stand_step(st)
+        torch.cuda.synchronize()
+        out, status = out.cpu().numpy(), status.cpu().numpy()
+        assert (status[:, 2] == 0).all()
+        assert np.abs(out[:, dead]).max() == 0.0
+        for i in range(B):
+            o = oracle_system(cfg2["dt"], cfg2["th"])
+            zx, zy = o.zmp()
+            o.set_refs(zx, zy, np.full(len(zx), ph, dtype=np.uint8))
+            e = o.eval(cfg2["q0"], v[i], 0.0)
+            assert rel_err(out[i, :24], e["tau"]) < TOL_REL
+            assert np.abs(out[i, 24:36] - e["f"]).max() < TOL_REL * max(1.0, np.abs(e["f"]).max())
+
+
+def test_domain_randomised_models(cfg2):
+    """Per-instance link parameters (mass x U(0.9,1.1), CoM +- 5 mm) through lmh_set_model."""
+    from linearmpchumanoid_amd.controller import nominal_links
+    B = 6
+    raw = np.tile(nominal_links(), (B, 1, 1))
+    rng = np.random.default_rng(20260004)
+    raw[:, :, 0] *= rng.uniform(0.9, 1.1, (B, 28))
+    raw[:, :, 1:4] += rng.uniform(-5e-3, 5e-3, (B, 28, 3)) * (raw[:, :, 0:1] > 0)
+    v = perturbed_velocities(B, seed=41) * 0.2
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=0)
+    ctl.set_refs_stance(2.0, 2)
+    ctl.set_model(raw)
+    st = ctl.new_state(cfg2["q0"], v, t=0.0)
+    out, status = ctl.stand_step(st)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    masses = ctl.mass()
+    from oracle.pyoracle import Oracle
+    for i in range(B):
+        o = Oracle(sim_time=2.0, dt=cfg2["dt"], horizon_time=cfg2["th"], do_ik=False, raw_links=raw[i])
+        assert abs(masses[i] - o.mass) < 1e-13
+        o.set_zcom(cfg2["zcom"])          # same LIPM height as the GPU handle
+        e = o.eval(cfg2["q0"], v[i], 0.0)
+        assert rel_err(out[i, :24], e["tau"]) < TOL_REL and rel_err(out[i, 24:36], e["f"]) < TOL_REL
+
+
+def test_ik_matches_oracle_posture():
+    """Kinematics::compute on the GPU: same posture and the same 4 Newton steps as the oracle."""
+    import json
+    ik = json.load(open(os.path.join(GOLD, "ik_posture.json")))
+    from oracle.pyoracle import Oracle
+    q_init = Oracle(do_ik=False).robot()["q"]
+    ctl = make_controller(3, 0.01, 0.5, 0.26)
+    q = torch.as_tensor(np.tile(q_init, (3, 1))).to(ctl.device)
+    q, iters = ctl.ik(q)
+    torch.cuda.synchronize()
+    qn = q.cpu().numpy()
+    assert (iters.cpu().numpy() == 4).all()
+    assert np.abs(qn - np.array(ik["q"])).max() < 1e-11
+
+
+# ------------------------------------------------------------------------------- full size
+def test_full_size_properties_config2(cfg2):
+    """B = 1024 (BASELINE configs[1]): properties that hold for every instance without an oracle run:
+    floating-base rows of the dynamics vanish at the QP solution, contact wrenches lie in the
+    friction cones, instance order does not matter, warm start == cold start."""
+    from linearmpchumanoid_amd.controller import unpack_debug
+    B = 1024
+    v = perturbed_velocities(B)
+    res = {}
+    for warm in (0, 1):
+        ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=warm)
+        ctl.set_refs_stance(2.0, 2)
+        st = ctl.new_state(cfg2["q0"], v, t=0.0)
+        out, status, _ = ctl.rollout(st, 5)
+        out2, status2, dbg = ctl.stand_step(st, debug=True)
+        torch.cuda.synchronize()
+        res[warm] = (out.cpu().numpy(), st.cpu().numpy(), out2.cpu().numpy(), dbg.cpu().numpy(), status2.cpu().numpy())
+    out_c, st_c, ev_c, dbg_c, status_c = res[0]
+    out_w, st_w, ev_w, _, _ = res[1]
+    assert (status_c[:, 2] == 0).all()
+    # warm start reaches the same (unique) minimiser
+    assert np.abs(out_w[:, :36] - out_c[:, :36]).max() < 1e-7 * np.abs(out_c[:, :36]).max()
+    assert np.abs(st_w[:, :60] - st_c[:, :60]).max() < 1e-9 * np.abs(st_c[:, :60]).max()
+    mu = 0.7
+    for i in range(0, B, 7):
+        d = unpack_debug(dbg_c[i]); dd = dense_terms_from_debug(d)
+        x = d["a"]; f = ev_c[i, 24:36]
+        resid = dd["M"][:6] @ x + d["C"][:6] - dd["J"].T[:6] @ f
+        assert np.abs(resid).max() < 1e-8 * np.abs(d["C"][:6]).max()
+        assert d["c"].min() > -1e-7 * max(1.0, d["c"].max())
+        for ft in range(2):
+            fx, fy, fz = f[6 * ft + 3: 6 * ft + 6]
+            assert fz > -1e-7 and abs(fx) <= mu * fz + 1e-7 and abs(fy) <= mu * fz + 1e-7
+    # permutation invariance: reversed instance order gives reversed results, bit for bit
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=0)
+    ctl.set_refs_stance(2.0, 2)
+    st = ctl.new_state(cfg2["q0"], v[::-1].copy(), t=0.0)
+    out_r, _, _ = ctl.rollout(st, 5)
+    torch.cuda.synchronize()
+    assert np.array_equal(out_r.cpu().numpy()[::-1], out_c)
+
+
+def test_full_size_sample_against_oracle(cfg2):
+    """B = 1024, 4 ticks: every 64th instance checked against its own oracle rollout."""
+    B = 1024
+    v = perturbed_velocities(B)
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=1)
+    ctl.set_refs_stance(2.0, 2)
+    st = ctl.new_state(cfg2["q0"], v, t=0.0)
+    out, status, _ = ctl.rollout(st, 4)
+    torch.cuda.synchronize()
+    out, stn, status = out.cpu().numpy(), st.cpu().numpy(), status.cpu().numpy()
+    for i in range(0, B, 64):
+        o = oracle_system(cfg2["dt"], cfg2["th"])
+        r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, 4, log=True)
+        assert status[i, 0] == r["k"][-1]
+        assert rel_err(out[i, :24], r["log"][-1][:24]) < TOL_REL and rel_err(out[i, 24:36], r["log"][-1][24:]) < TOL_REL
+        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-8

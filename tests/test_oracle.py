@@ -1,0 +1,176 @@
+"""CPU tests of the oracle itself (no GPU): survey anchors, internal invariants, KKT of every QP,
+committed golden fixtures.  The reference ships no tests/golden vectors ("parity unpinned")."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import oracle_system, perturbed_velocities, rel_err
+from oracle.pyoracle import Oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def offline():
+    return Oracle(sim_time=5.0, dt=0.01, horizon_time=0.5, do_ik=True)
+
+
+def test_survey_anchors(offline):
+    """Non-authoritative anchors of SURVEY.md 8c (independent numpy transliteration of the reference)."""
+    o0 = Oracle(do_ik=False)
+    assert abs(o0.mass - 5.30539) < 1e-12
+    assert np.allclose(o0.robot()["CoM"], [-8.706522035742e-3, 0.0, 0.2580191806516], atol=1e-12)
+    r = offline.robot()
+    assert np.allclose(r["CoM"], [-0.02, 0.0, 0.26], atol=1e-10)
+    assert np.allclose(r["q"][:3], [-3.238212783577e-2, 0.0, 0.2844164073123], atol=1e-11)
+    assert np.allclose(r["q"][8:11], [-0.5041385338198, 0.6595073262801, -0.1553687924601], atol=1e-11)
+    assert offline.horizon == 50 and offline.n_zmp == 550
+    K = offline.gain_row()
+    Px, Pu = offline.mpc_mats()
+    assert abs(Pu[0, 0] - (-0.0265035677879715)) < 1e-14
+    assert abs(K[0] - (-14.39564980491)) < 1e-8 and abs(K[1] - 1.134304133175) < 1e-9
+    assert abs(K.sum() - 20.85545314111) < 1e-8
+    assert np.allclose(K @ Px, [20.85545314111, 7.706753397498], atol=1e-8)
+    e = offline.eval(r["q"], np.zeros(30), 0.0)
+    assert e["k"] == 0 and e["qp_status"] == 0 and e["active_mask"] == 0
+    assert abs(offline.qp()["u0"][0] - 0.417109) < 1e-6
+    f_ref = [-7.180185e-5, 0.7950184837, -2.398258e-4, 1.199450113, -3.7e-9, 25.92505445,
+             -7.180185e-5, 0.7950184837, -2.398258e-4, 1.199474099, -3.7e-9, 25.92504727]
+    assert np.allclose(e["f"], f_ref, atol=2e-8)
+    assert abs(e["tau"][3] - (-1.014091330871)) < 1e-10 and abs(e["tau"][9] - (-1.014083780437)) < 1e-10
+    t = offline.terms()
+    assert abs(t["C"][5] - 52.04299827) < 1e-7          # not m*g = 52.0459 (0.7071 literal)
+    assert abs(t["AG"][4, 4] - 5.305096663) < 1e-8      # not m = 5.30539
+    x = offline.qp()["x"]
+    assert 0.20 < x[42:].min() and x[42:].max() < 3.05
+
+
+def test_mass_matrix_asymmetry_and_structure(offline):
+    """Quirks that must survive: asymmetric base block, symmetric joint block."""
+    r = offline.robot()
+    offline.eval(r["q"], np.zeros(30), 0.0)
+    M = offline.terms()["M"]
+    asym = np.abs(M[:6, :6] - M[:6, :6].T).max()
+    assert 1e-5 < asym < 2e-4
+    assert np.abs(M[6:, 6:] - M[6:, 6:].T).max() == 0.0
+    assert np.array_equal(M[:6, 6:], M[6:, :6].T)
+    assert np.abs(M[6:12, 12:18]).max() == 0.0          # legs couple only through the base
+
+
+def kkt_check(qp, tol=1e-7):
+    H, g, A, lb, ub, x = qp["H"], qp["g"], qp["A"], qp["lbA"], qp["ubA"], qp["x"]
+    r = H @ x + g
+    Ax = A @ x
+    eq = lb == ub
+    assert np.abs(Ax[eq] - lb[eq]).max() < 1e-9 * max(1, np.abs(x).max())
+    if (~eq).any():
+        assert (Ax[~eq] - lb[~eq]).min() > -1e-8 * max(1, np.abs(x).max())
+    act = eq | (Ax - lb < 1e-8)
+    lam, *_ = np.linalg.lstsq(A[act].T, r, rcond=None)
+    assert np.abs(A[act].T @ lam - r).max() < tol * max(1.0, np.abs(r).max())
+    lam_in = lam[~eq[act]]
+    if lam_in.size:
+        assert lam_in.min() > -tol * max(1.0, np.abs(lam).max())
+
+
+def test_qp_kkt_on_perturbed_states():
+    """Every QP solution must satisfy the KKT conditions (sufficient for the unique minimiser)."""
+    o = oracle_system(1e-3, 0.016)
+    q0 = o.robot()["q"].copy()
+    v = perturbed_velocities(24)
+    n_active = []
+    for i in range(24):
+        o.set_prev_velocity(v[i])
+        e = o.eval(q0, v[i], 0.0)
+        assert e["qp_status"] == 0
+        kkt_check(o.qp())
+        n_active.append(bin(e["active_mask"]).count("1"))
+    assert max(n_active) >= 16          # pushes saturate the friction cones
+
+
+def test_base_rows_of_dynamics_vanish(offline):
+    """rows 0..5 of M qdd + C - J'f are the QP's equality rows (controller.cpp:138-140 discards them)."""
+    r = offline.robot()
+    v = perturbed_velocities(1)[0]
+    offline.set_prev_velocity(v)
+    e = offline.eval(r["q"], v, 0.0)
+    qp, t = offline.qp(), offline.terms()
+    res = t["M"][:6] @ qp["x"][:30] + t["C"][:6] - t["J"].T[:6] @ e["f"]
+    assert np.abs(res).max() < 1e-9 * np.abs(t["C"][:6]).max()
+
+
+def test_stale_velocity_quirk(offline):
+    """C, Cg, Jpqp use Robot::v_ of the PREVIOUS standStep (controller.cpp:56 before :59)."""
+    r = offline.robot()
+    v = perturbed_velocities(1, seed=5)[0]
+    offline.set_prev_velocity(np.zeros(30))
+    offline.eval(r["q"], v, 0.0)
+    c_first = offline.terms()["C"].copy()
+    offline.eval(r["q"], v, 0.0)        # now Robot::v_ == v
+    c_second = offline.terms()["C"].copy()
+    assert np.abs(c_first - c_second).max() > 1e-6
+    o2 = Oracle(do_ik=True)
+    o2.set_prev_velocity(v)
+    o2.eval(r["q"], v, 0.0)
+    assert np.allclose(o2.terms()["C"], c_second, rtol=0, atol=1e-14)
+
+
+def test_k_sequence_matches_fixture():
+    """k = int(t/dt) on the float-accumulated clock lags the ideal index on many ticks (A5)."""
+    ks = np.load(os.path.join(GOLD, "k_sequences.npz"))
+    for name, dt, n in (("dt_0p01", 0.01, 500), ("dt_0p001", 0.001, 5000)):
+        seq = ks[name]
+        t = 0.0
+        for i in range(n):
+            assert seq[i, 0] == int(t / dt) and seq[i, 3] == int((t + dt) / dt)
+            t += dt
+        lag = int((seq[:, 0] != np.arange(n)).sum())
+        assert lag > 0
+
+
+def test_golden_eval_vectors():
+    g = np.load(os.path.join(GOLD, "eval_vectors.npz"))
+    for i in range(g["q"].shape[0]):
+        o = Oracle(sim_time=5.0, dt=float(g["dt"]), horizon_time=float(g["time_horizon"]), do_ik=True)
+        o.set_prev_velocity(g["v_prev"][i])
+        e = o.eval(g["q"][i], g["v"][i], float(g["t"]))
+        assert e["k"] == int(g["k"][i])
+        assert rel_err(e["tau"], g["tau"][i]) < 1e-12 and rel_err(e["f"], g["f"][i]) < 1e-12
+        t = o.terms()
+        assert rel_err(t["M"], g["M"][i]) < 1e-13 and rel_err(t["C"], g["C"][i]) < 1e-13
+
+
+def test_golden_offline_trace():
+    """apps/offline workload: 500 ticks, CoM x printed after each tick (k4-stage Robot state)."""
+    g = np.load(os.path.join(GOLD, "offline_trace.npz"))
+    o = Oracle(sim_time=5.0, dt=0.01, horizon_time=0.5, do_ik=True)
+    q0 = o.robot()["q"].copy()
+    r = o.rollout(np.concatenate([q0, np.zeros(30)]), 0.0, 120)
+    assert np.array_equal(r["k"], g["k"][:120])
+    assert np.abs(r["comx"] - g["comx"][:120]).max() < 1e-13
+    assert abs(g["comx"][-1] - (-1.34e-4)) < 1e-6           # survey anchor
+    assert abs(g["tau_f_last"][24 + 5] + g["tau_f_last"][24 + 11] - 52.04998) < 1e-4
+
+
+def test_duplicate_wbc_is_result_neutral(offline):
+    """apps/offline/main.cpp:103-105 calls WBC twice per evaluation; the result does not change."""
+    r = offline.robot()
+    st = np.concatenate([r["q"], perturbed_velocities(1, seed=9)[0]])
+    a = Oracle(do_ik=True); b = Oracle(do_ik=True)
+    b.set_wbc_calls(2, faithful=True)
+    ra = a.rollout(st, 0.0, 3, log=True); rb = b.rollout(st, 0.0, 3, log=True)
+    assert np.array_equal(ra["state"], rb["state"]) and np.array_equal(ra["log"], rb["log"])
+
+
+def test_support_phase_extension():
+    """Build-defined: a foot out of support carries no wrench (coefficients pinned to zero)."""
+    o = Oracle(do_ik=True)
+    q0 = o.robot()["q"].copy()
+    zx, zy = o.zmp()
+    for ph, dead in ((1, slice(6, 12)), (2, slice(0, 6)), (3, slice(0, 12))):
+        o.set_refs(zx, zy, np.full(len(zx), ph, dtype=np.uint8))
+        e = o.eval(q0, np.zeros(30), 0.0)
+        assert e["qp_status"] == 0 and e["phase"] == ph
+        assert np.abs(e["f"][dead]).max() < 1e-9
+        kkt_check(o.qp())
