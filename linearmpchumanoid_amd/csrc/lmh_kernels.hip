@@ -30,28 +30,6 @@
 #define WSYNC() __syncthreads()
 
 // ------------------------------------------------------------------ constant tables
-// Robot.cpp:162-174
-__constant__ int8_t c_parent[28] = {-1, 0, 1, 2, 3, 4, 5, 6, 0, 8, 9, 10, 11, 12, 13, 0, 15, 16, 17, 18, 0, 20, 21, 22, 23, 0, 25, 26};
-__constant__ int8_t c_act[28] = {0, 1, 2, 3, 4, 5, 6, 0, 7, 8, 9, 10, 11, 12, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 0};
-// frame -> slot of its local transform (Temp[] index of Robot.cpp:120-158; 27 = sole offset)
-__constant__ int8_t c_loc[28] = {-1, 0, 1, 2, 3, 4, 5, 27, 6, 7, 8, 9, 10, 11, 27, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24};
-// body list (frames with mass): base + 24 actuated
-__constant__ int8_t c_body[25] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26};
-// actuated joint a (0..23) -> frame
-__constant__ int8_t c_jframe[24] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26};
-// actuated joint a -> depth in its chain (1 = child of the base), limb start joint
-__constant__ int8_t c_jdepth[24] = {1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 1, 2};
-__constant__ int8_t c_jstart[24] = {0, 0, 0, 0, 0, 0, 6, 6, 6, 6, 6, 6, 12, 12, 12, 12, 12, 17, 17, 17, 17, 17, 22, 22};
-// chain c, depth d (1..7) -> frame, -1 = none (legs include the sole at depth 7)
-__constant__ int8_t c_chain[5][7] = {{1, 2, 3, 4, 5, 6, 7}, {8, 9, 10, 11, 12, 13, 14}, {15, 16, 17, 18, 19, -1, -1},
-                                     {20, 21, 22, 23, 24, -1, -1}, {25, 26, 27, -1, -1, -1, -1}};
-// FK schedule: chain c, step s -> dst, src T slot, local slot (T slots 28/29 = T0*auxT01 / T0*auxT09)
-__constant__ int8_t c_fk_dst[5][8] = {{28, 1, 2, 3, 4, 5, 6, 7}, {29, 8, 9, 10, 11, 12, 13, 14}, {15, 16, 17, 18, 19, -1, -1, -1},
-                                      {20, 21, 22, 23, 24, -1, -1, -1}, {25, 26, 27, -1, -1, -1, -1, -1}};
-__constant__ int8_t c_fk_src[5][8] = {{0, 28, 1, 2, 3, 4, 5, 6}, {0, 29, 8, 9, 10, 11, 12, 13}, {0, 15, 16, 17, 18, -1, -1, -1},
-                                      {0, 20, 21, 22, 23, -1, -1, -1}, {0, 25, 26, -1, -1, -1, -1, -1}};
-__constant__ int8_t c_fk_loc[5][8] = {{25, 0, 1, 2, 3, 4, 5, 27}, {26, 6, 7, 8, 9, 10, 11, 27}, {12, 13, 14, 15, 16, -1, -1, -1},
-                                      {17, 18, 19, 20, 21, -1, -1, -1}, {22, 23, 24, -1, -1, -1, -1, -1}};
 // Khalil modified-DH tables, Robot.cpp:180-196.  cos/sin(alpha) are the values libm returns for
 // the reference's literal pi (cos(+-pi/2) = 6.123233995736766e-17, kept: SURVEY appendix A3).
 #define CPI2 6.123233995736766e-17
@@ -67,19 +45,44 @@ __constant__ double c_dh_off[24] = {0, (3.0 / 4) * RPI, 0, 0, 0, 0, -(1.0 / 2) *
 __constant__ double c_aux[3][12] = {{0, -1, 0, 0, 0.7071, 0, 0.7071, 0, -0.7071, 0, 0.7071, 0},
                                     {1, 0, 0, 0, 0, 0.7071, 0.7071, 0, 0, -0.7071, 0.7071, 0},
                                     {1, 0, 0, -0.0452, 0, 1, 0, 0, 0, 0, 1, 0}};
-// shoulder / head offsets added to the translation of Temp[12], Temp[17], Temp[22] (Robot.cpp:134-154)
-__constant__ double c_off_y[3] = {-0.098, 0.098, 0.0};
-__constant__ double c_off_z[3] = {0.13591, 0.13591, 0.1615};
-// Robot::desiredPosture, Robot.cpp:253-262
-__constant__ double c_qdes[30] = {-0.0185, 0, 0.282, 0, 0, 0, 0, 0, -0.5, 0.8, -0.3, 0, 0, 0, -0.5, 0.8, -0.3, 0,
-                                  1.6, 0, 0, 0, 0, -1.6, 0, 0, 0, 0, 0, 0};
 // Rf_q0_, Robot.cpp:28-31
 __constant__ double c_rdes[9] = {0, 0, 1, 0, -1, 0, 1, 0, 0};
-// CRBA levels: frames at chain depth 6..2 (depth 1 handled separately, parent = base)
-__constant__ int8_t c_lvl[5][5] = {{6, 13, -1, -1, -1}, {5, 12, 19, 24, -1}, {4, 11, 18, 23, -1}, {3, 10, 17, 22, -1}, {2, 9, 16, 21, 26}};
-__constant__ int8_t c_lvln[5] = {2, 4, 4, 4, 5};
-// base children in the order the reference accumulates them (i = 27 -> 1): head, LA, RA, LL, RL
-__constant__ int8_t c_roots[5] = {25, 20, 15, 8, 1};
+
+
+// ------------------------------------------------------------------ index maps (pure arithmetic:
+// a per-lane __constant__ lookup is a global load, ~500 cycles of latency at one wave per SIMD)
+__device__ __forceinline__ int f_parent(int i) { return (i == 1 || i == 8 || i == 15 || i == 20 || i == 25) ? 0 : i - 1; }   // Robot.cpp:165
+__device__ __forceinline__ int f_act(int i) { return (i == 0 || i == 7 || i == 14 || i == 27) ? 0 : (i < 7) ? i : (i < 14) ? i - 1 : i - 2; }  // Robot.cpp:172
+__device__ __forceinline__ int f_jframe(int a) { return (a < 6) ? a + 1 : (a < 12) ? a + 2 : a + 3; }
+__device__ __forceinline__ int f_jstart(int a) { return (a < 6) ? 0 : (a < 12) ? 6 : (a < 17) ? 12 : (a < 22) ? 17 : 22; }
+__device__ __forceinline__ int f_jdepth(int a) { return a - f_jstart(a) + 1; }
+__device__ __forceinline__ int f_body(int b) { return (b < 7) ? b : (b < 13) ? b + 1 : b + 2; }
+__device__ __forceinline__ int f_chain_base(int c) { return (c == 0) ? 1 : (c == 1) ? 8 : (c == 2) ? 15 : (c == 3) ? 20 : 25; }
+__device__ __forceinline__ int f_chain_len(int c) { return (c < 2) ? 7 : (c < 4) ? 5 : 3; }
+__device__ __forceinline__ int f_chain(int c, int d) { return (d < f_chain_len(c)) ? f_chain_base(c) + d : -1; }
+// FK schedule (Robot.cpp:120-158): chain c, step s -> dst / src T slot, local-transform slot
+__device__ __forceinline__ void fk_sched(int c, int s, int *dst, int *src, int *loc)
+{
+    const int base = f_chain_base(c);
+    if (c < 2) {                        // legs: T0*aux, six joints, sole
+        if (s == 0) { *dst = 28 + c; *src = 0; *loc = 25 + c; }
+        else if (s < 7) { *dst = base + s - 1; *src = (s == 1) ? 28 + c : base + s - 2; *loc = 6 * c + s - 1; }
+        else { *dst = base + 6; *src = base + 5; *loc = 27; }
+    } else if (c < 4) {                 // arms
+        if (s < 5) { *dst = base + s; *src = (s == 0) ? 0 : base + s - 1; *loc = 12 + 5 * (c - 2) + s; }
+        else *dst = -1;
+    } else {                            // head (+ extra head frame)
+        if (s < 3) { *dst = 25 + s; *src = (s == 0) ? 0 : 24 + s; *loc = 22 + s; }
+        else *dst = -1;
+    }
+}
+// Robot::desiredPosture (Robot.cpp:253-262)
+__device__ __forceinline__ double qdes_of(int i)
+{
+    return (i == 0) ? -0.0185 : (i == 2) ? 0.282 : (i == 8 || i == 14) ? -0.5 : (i == 9 || i == 15) ? 0.8
+         : (i == 10 || i == 16) ? -0.3 : (i == 18) ? 1.6 : (i == 23) ? -1.6 : 0.0;
+}
+__device__ __forceinline__ int f_root(int r) { return (r == 0) ? 25 : (r == 1) ? 20 : (r == 2) ? 15 : (r == 3) ? 8 : 1; }  // reference order: head, LA, RA, LL, RL
 
 // ------------------------------------------------------------------ LDS map (doubles)
 enum {
@@ -94,7 +97,8 @@ enum {
     P_Y = 1452,       // 30 x 7 : H^-1 [g | Mb']
     P_SI = 1662, P_D6 = 1698, P_W = 1704, P_H12 = 1848, P_QV = 1860, P_CC = 1892, P_LAM = 1924,
     P_W12 = 1956, P_LAM6 = 1968, P_A = 1974, P_GCOL = 2004, P_TAU = 2196, P_QDD = 2220,
-    P_END = 2252,
+    P_TAB = 2252,     // DH r|d|cos a|sin a (4x25), theta offsets (24), fixed transforms (36)
+    P_END = 2412,
     // ---- scratch, phase A1 (kinematics + Newton-Euler)
     S0 = P_END,
     A_LC = S0 + 0,    // 28 x 12 local transforms (dead after FK)
@@ -113,6 +117,7 @@ enum {
     B_BP = S0 + 1016, // 30 x 7
     B_S = S0 + 1226,  // 12 x 7
     B_T1 = S0 + 1310, // 12 x 6
+    B_OB = S0 + 1382, // Om*beta (18) | 1/Om (18)
     // ---- phase C (cone QP)
     C_WG = S0 + 0,    // 12 x 32
     C_P = S0 + 384,   // 32 x 32
@@ -157,46 +162,51 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
-// In-place Cholesky of the leading n x n block of K (lower, row stride ld) carrying m extra
-// rows n..n+m-1 along: on exit row n+r holds (L^-1 v_r)'.  Returns a wave-uniform flag
-// (non-zero if a pivot was not positive).  n, m wave-uniform.
-__device__ int chol_aug(double *K, int ld, int n, int m)
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);            // v_rcp_f64 (~2^-26) + two Newton steps -> full fp64
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return y;
+}
+
+// In-place LDL' of the leading n x n block of K (lower triangle, row stride ld) carrying m extra
+// rows n..n+m-1 along (n + m <= 33).  On exit K[j][j] = d_j, K[i][j] = L_ij (unit lower) and extra
+// row n+r holds D^-1 L^-1 v_r.  Lane map: row = pivot+1+(lane&31), the two half-waves split the
+// columns by parity -- no integer division, one wave fence per pivot.  Returns non-zero (wave-uniform)
+// if a pivot was not positive.  n, m wave-uniform.
+__device__ int ldl_aug(double *K, int ld, int n, int m)
 {
     int bad = 0;
-    const int rows = n + m;
+    const int rows = n + m, r = LANE & 31, half = LANE >> 5;
     for (int j = 0; j < n; j++) {
         WSYNC();
         const double d = K[j * ld + j];
         if (!(d > 0.0)) bad = 1;
-        const double invd = 1.0 / d;
-        const int nr = rows - j - 1;          // rows below the pivot
-        const int nc = n - j - 1;             // columns right of the pivot
-        // trailing update with the UNSCALED pivot column: K[i][c] -= K[i][j] K[c][j] / d   (c <= i when i < n)
-        for (int e = LANE; e < nr * nc; e += 64) {
-            const int i = j + 1 + e / nc, c = j + 1 + e % nc;
-            if (i >= n || c <= i) K[i * ld + c] -= K[i * ld + j] * K[c * ld + j] * invd;
+        const double invd = fast_rcp(d);
+        const int i = j + 1 + r;
+        double f = 0.0;
+        if (i < rows) {
+            f = K[i * ld + j] * invd;
+            const int cend = (i < n) ? i : n - 1;
+            double *Ki = K + i * ld;
+            for (int c = j + 1 + half; c <= cend; c += 2) Ki[c] -= f * K[c * ld + j];   // K[c][j] still d_j L_cj
         }
-        WSYNC();
-        const double s = sqrt(d), invs = 1.0 / s;
-        for (int i = j + 1 + LANE; i < rows; i += 64) K[i * ld + j] *= invs;
-        if (LANE == 0) K[j * ld + j] = s;
+        if (i < rows && half == 0) K[i * ld + j] = f;           // after every lane's reads of column j
     }
     WSYNC();
     return bad;
 }
-// Solve L' t = y in place for the m extra rows (each a length-n vector stored in row n+r).
-__device__ void chol_back(double *K, int ld, int n, int m)
+// Solve L' x = w in place for the m extra rows (w = D^-1 L^-1 v from ldl_aug).
+__device__ void ldl_back(double *K, int ld, int n, int m)
 {
-    for (int j = n - 1; j >= 0; j--) {
+    const int i = LANE & 31, half = LANE >> 5;
+    for (int j = n - 1; j > 0; j--) {
         WSYNC();
-        const double inv = 1.0 / K[j * ld + j];
-        // t_j = y_j / L_jj ; y_i -= L[j][i] t_j  (i < j)
-        for (int e = LANE; e < m * j; e += 64) {
-            const int r = e / j, i = e % j;
-            K[(n + r) * ld + i] -= K[j * ld + i] * (K[(n + r) * ld + j] * inv);
+        if (i < j) {
+            const double lji = K[j * ld + i];
+            for (int r = half; r < m; r += 2) K[(n + r) * ld + i] -= lji * K[(n + r) * ld + j];
         }
-        WSYNC();
-        for (int r = LANE; r < m; r += 64) K[(n + r) * ld + j] *= inv;
     }
     WSYNC();
 }
@@ -209,7 +219,7 @@ __device__ void phase_fk(double *L)
     const int lane = LANE;
     if (lane < 28) {
         double s, c;
-        if (lane < 24) sincos(L[P_Q + 6 + lane] + c_dh_off[lane], &s, &c);
+        if (lane < 24) sincos(L[P_Q + 6 + lane] + L[P_TAB + 100 + lane], &s, &c);
         else if (lane == 24) { s = -1.0; c = CPI2; }              // theta[24] = -pi/2 (Robot.cpp:87)
         else sincos(L[P_Q + 3 + (lane - 25)], &s, &c);            // roll, pitch, yaw
         L[P_SC + 2 * lane] = s;
@@ -221,18 +231,18 @@ __device__ void phase_fk(double *L)
         double val;
         if (s < 25) {
             const double st = L[P_SC + 2 * s], ct = L[P_SC + 2 * s + 1];
-            const double ca = c_dh_ca[s], sa = c_dh_sa[s], dd = c_dh_d[s], rr = c_dh_r[s];
+            const double ca = L[P_TAB + 50 + s], sa = L[P_TAB + 75 + s], dd = L[P_TAB + 25 + s], rr = L[P_TAB + s];
             if (r == 0) val = (col == 0) ? ct : (col == 1) ? -st : (col == 2) ? 0.0 : dd;
             else if (r == 1) val = (col == 0) ? ca * st : (col == 1) ? ca * ct : (col == 2) ? -sa : -rr * sa;
             else val = (col == 0) ? sa * st : (col == 1) ? sa * ct : (col == 2) ? ca : rr * ca;
             if (col == 3 && (s == 12 || s == 17 || s == 22)) {
                 const int o = (s == 12) ? 0 : (s == 17) ? 1 : 2;
                 if (r == 0) val = val + 0.0;
-                else if (r == 1) val = val + c_off_y[o];
-                else val = val + c_off_z[o];
+                else if (r == 1) val = val + ((o == 0) ? -0.098 : (o == 1) ? 0.098 : 0.0);      // Robot.cpp:134,143,152
+                else val = val + ((o == 2) ? 0.1615 : 0.13591);
             }
         } else {
-            val = c_aux[s - 25][el];
+            val = L[P_TAB + 124 + 12 * (s - 25) + el];
         }
         L[A_LC + e] = val;
     }
@@ -250,10 +260,11 @@ __device__ void phase_fk(double *L)
     for (int s = 0; s < 8; s++) {
         WSYNC();
         if (lane < 60) {
-            const int dst = c_fk_dst[c][s];
+            int dst, src, loc;
+            fk_sched(c, s, &dst, &src, &loc);
             if (dst >= 0) {
-                const double *Ts = L + A_T + 12 * c_fk_src[c][s] + 4 * r;
-                const double *Lo = L + A_LC + 12 * c_fk_loc[c][s] + col;
+                const double *Ts = L + A_T + 12 * src + 4 * r;
+                const double *Lo = L + A_LC + 12 * loc + col;
                 double val = Ts[0] * Lo[0] + Ts[1] * Lo[4] + Ts[2] * Lo[8];
                 if (col == 3) val += Ts[3];
                 L[A_T + 12 * dst + el] = val;
@@ -291,7 +302,7 @@ __device__ void phase_com_x(double *L)
         if (i == 0) {
             val = (el < 9) ? Ti[(el / 3) * 4 + el % 3] : Ti[(el - 9) * 4 + 3];
         } else {
-            const double *Tp = L + A_T + 12 * c_parent[i];
+            const double *Tp = L + A_T + 12 * f_parent(i);
             if (el < 9) {
                 const int a = el / 3, b = el % 3;
                 val = Tp[a] * Ti[b] + Tp[4 + a] * Ti[4 + b] + Tp[8 + a] * Ti[8 + b];
@@ -350,11 +361,11 @@ __device__ void phase_newton_euler(double *L)
         for (int d = 0; d < 6; d++) {
             WSYNC();
             if (lane < 30) {
-                const int i = c_chain[c][d];
-                if (i >= 0 && c_act[i] != 0) {
-                    const double *vp = L + A_VEL + 6 * c_parent[i];
+                const int i = f_chain(c, d);
+                if (i >= 0 && f_act(i) != 0) {
+                    const double *vp = L + A_VEL + 6 * f_parent(i);
                     double val = x_mot(L + A_XE + 9 * i, L + A_XB + 9 * i, vp, k);
-                    if (k == 2) val += L[P_VHS + 5 + c_act[i]];
+                    if (k == 2) val += L[P_VHS + 5 + f_act(i)];
                     L[A_VEL + 6 * i + k] = val;
                 }
             }
@@ -366,13 +377,13 @@ __device__ void phase_newton_euler(double *L)
         for (int d = 0; d < 7; d++) {
             WSYNC();
             if (lane < 60) {
-                const int i = c_chain[c][d];
+                const int i = f_chain(c, d);
                 if (i >= 0 && !(c == 4 && d == 2)) {
-                    const double *ap = L + base + 6 * c_parent[i];
+                    const double *ap = L + base + 6 * f_parent(i);
                     double val = x_mot(L + A_XE + 9 * i, L + A_XB + 9 * i, ap, k);
-                    if (c_act[i] != 0) {
+                    if (f_act(i) != 0) {
                         const double *vi = L + A_VEL + 6 * i;
-                        const double qd = L[P_VHS + 5 + c_act[i]];
+                        const double qd = L[P_VHS + 5 + f_act(i)];
                         // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
                         const double cs = (k == 0) ? vi[1] : (k == 1) ? -vi[0] : (k == 3) ? vi[4] : (k == 4) ? -vi[3] : 0.0;
                         val += cs * qd;
@@ -385,7 +396,7 @@ __device__ void phase_newton_euler(double *L)
     WSYNC();
     // body forces f = I a + v x* (I v), one lane per (body, which)
     if (lane < 50) {
-        const int which = lane / 25, i = c_body[lane % 25];
+        const int which = lane / 25, i = f_body(lane % 25);
         const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
         const double *v = L + A_VEL + 6 * i, *a = L + (which ? A_ACC0 : A_ACCG) + 6 * i;
         const double m = mo[12], hx = mo[9], hy = mo[10], hz = mo[11];
@@ -419,9 +430,9 @@ __device__ void phase_newton_euler(double *L)
         for (int d = 5; d >= 1; d--) {
             WSYNC();
             if (lane < 60) {
-                const int i = c_chain[c][d];
-                if (i >= 0 && c_act[i] != 0) {
-                    const int p = c_parent[i];
+                const int i = f_chain(c, d);
+                if (i >= 0 && f_act(i) != 0) {
+                    const int p = f_parent(i);
                     L[base + 6 * p + k] += x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + base + 6 * i, k);
                 }
             }
@@ -431,12 +442,12 @@ __device__ void phase_newton_euler(double *L)
             const int w2 = lane / 6, k2 = lane % 6, b2 = w2 ? A_F0 : A_FG;
             double acc = L[b2 + k2];
             for (int r = 0; r < 5; r++) {
-                const int i = c_roots[r];
+                const int i = f_root(r);
                 acc += x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + b2 + 6 * i, k2);
             }
             if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc;
         }
-        if (lane >= 16 && lane < 40) L[P_C + 6 + (lane - 16)] = L[A_FG + 6 * c_jframe[lane - 16] + 2];
+        if (lane >= 16 && lane < 40) L[P_C + 6 + (lane - 16)] = L[A_FG + 6 * f_jframe(lane - 16) + 2];
         if (lane >= 40 && lane < 52) {                             // Jpqp = blkdiag(R,R) acc0[sole]
             const int foot = (lane - 40) / 6, k2 = (lane - 40) % 6, r = k2 % 3, o = (k2 / 3) * 3;
             const double *T = L + P_TB + 12 * (1 + foot), *a = L + A_ACC0 + 6 * (foot ? 14 : 7);
@@ -452,7 +463,7 @@ __device__ void phase_crba(double *L)
     const int lane = LANE;
     // composite inertias start as the body inertias: [Ibar, [h]x; -[h]x, m 1]   (Dynamics.cpp:4-13)
     for (int e = lane; e < 25 * 36; e += 64) {
-        const int i = c_body[e / 36], r = (e % 36) / 6, c = e % 6;
+        const int i = f_body(e / 36), r = (e % 36) / 6, c = e % 6;
         const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
         double val;
         if (r < 3 && c < 3) val = mo[3 * r + c];
@@ -470,10 +481,11 @@ __device__ void phase_crba(double *L)
         L[A_IC + 36 * i + 6 * r + c] = val;
     }
     for (int lv = 0; lv < 5; lv++) {
-        const int nf = c_lvln[lv];
+        const int dl = 6 - lv;                                      // chain depth of this level (6..2)
+        const int nf = (dl == 6) ? 2 : (dl >= 3) ? 4 : 5;
         WSYNC();
         for (int e = lane; e < nf * 36; e += 64) {                 // Y = Ic_i X_i
-            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = c_lvl[lv][sl];
+            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = f_chain_base(sl) + dl - 1;
             const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
             double s = 0.0;
             if (c < 3) { for (int k = 0; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
@@ -482,17 +494,17 @@ __device__ void phase_crba(double *L)
         }
         WSYNC();
         for (int e = lane; e < nf * 36; e += 64) {                 // Ic_parent += X_i' Y
-            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = c_lvl[lv][sl];
+            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = f_chain_base(sl) + dl - 1;
             const double *Y = L + A_YT + 36 * sl + c, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
             double s = 0.0;
             if (r < 3) { for (int k = 0; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
             else { for (int k = 3; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
-            L[A_IC + 36 * c_parent[i] + 6 * r + c] += s;
+            L[A_IC + 36 * f_parent(i) + 6 * r + c] += s;
         }
     }
     WSYNC();
     for (int e = lane; e < 5 * 36; e += 64) {                      // depth-1 frames: Y
-        const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = c_roots[sl];
+        const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = f_root(sl);
         const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
         double s = 0.0;
         if (c < 3) { for (int k = 0; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
@@ -504,7 +516,7 @@ __device__ void phase_crba(double *L)
         const int r = lane / 6, c = lane % 6;
         double acc = L[A_IC + lane];
         for (int sl = 0; sl < 5; sl++) {
-            const int i = c_roots[sl];
+            const int i = f_root(sl);
             const double *Y = L + A_YT + 36 * sl + c, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
             double s = 0.0;
             if (r < 3) { for (int k = 0; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
@@ -517,24 +529,24 @@ __device__ void phase_crba(double *L)
     for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
     for (int e = lane; e < 144; e += 64) {
         const int a = e / 6, k = e % 6;
-        L[A_FB + e] = L[A_IC + 36 * c_jframe[a] + 6 * k + 2];
+        L[A_FB + e] = L[A_IC + 36 * f_jframe(a) + 6 * k + 2];
     }
     WSYNC();
-    if (lane < 24) L[P_HL + 6 * lane + (lane - c_jstart[lane])] = L[A_FB + 6 * lane + 2];
+    if (lane < 24) L[P_HL + 6 * lane + (lane - f_jstart(lane))] = L[A_FB + 6 * lane + 2];
     int cur = 0;
     for (int s = 1; s <= 6; s++) {
         WSYNC();
         for (int e = lane; e < 144; e += 64) {
-            const int a = e / 6, k = e % 6, dpt = c_jdepth[a];
+            const int a = e / 6, k = e % 6, dpt = f_jdepth(a);
             if (s <= dpt) {
-                const int j = c_jframe[a] - (s - 1);               // frame whose X' is applied
+                const int j = f_jframe(a) - (s - 1);               // frame whose X' is applied
                 const double val = x_force(L + A_XE + 9 * j, L + A_XB + 9 * j, L + A_FB + 144 * cur + 6 * a, k);
                 L[A_FB + 144 * (cur ^ 1) + e] = val;
                 if (s == dpt) L[P_MTOP + 30 * k + 6 + a] = val;    // F2 column
                 else if (k == 2) {
                     const int aj = a - s;                          // joint of parent(j)
-                    L[P_HL + 6 * aj + (a - c_jstart[a])] = val;
-                    L[P_HL + 6 * a + (aj - c_jstart[a])] = val;
+                    L[P_HL + 6 * aj + (a - f_jstart(a))] = val;
+                    L[P_HL + 6 * a + (aj - f_jstart(a))] = val;
                 }
             }
         }
@@ -645,7 +657,7 @@ __device__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, 
     }
     if (lane >= 32 && lane < 62) {                                 // PDJointsAcc, controller.cpp:296-308
         const int i = lane - 32;
-        const double val = P.kp_joints * (c_qdes[i] - L[P_Q + i]) + P.kd_joints * (0.0 - L[P_V + i]);
+        const double val = P.kp_joints * (qdes_of(i) - L[P_Q + i]) + P.kd_joints * (0.0 - L[P_V + i]);
         L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
     }
     WSYNC();
@@ -724,37 +736,42 @@ __device__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, 
 }
 
 
-// Solve P_FF z_F = qv_F on the free set F (compact Cholesky in C_PW).  Returns z_j for lane j in F
-// (0 otherwise) and, for lanes not in F, the multiplier lam_j = (P z - qv)_j.  idx[] = compact -> index.
+// Solve P_FF z_F = qv_F on the free set F (compact LDL' in C_PW).  Returns z_j for lane j in F
+// (0 otherwise) and, for lanes j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
 __device__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
 {
-    const int lane = LANE;
+    const int lane = LANE, r = lane & 31, half = lane >> 5;
     int *idx = (int *)(L + C_IDX);
     const int ldp = 33;
     int bad = 0;
     const int nF = __popc(F);
+    const int pos = __popc(F & ((1u << r) - 1u));
+    const bool inF = (F >> r) & 1u;
     WSYNC();
-    if (lane < 32 && ((F >> lane) & 1u)) idx[__popc(F & ((1u << lane) - 1u))] = lane;
+    if (lane < 32 && inF) idx[pos] = lane;
     WSYNC();
-    for (int e = lane; e < (nF + 1) * nF; e += 64) {
-        const int a = e / nF, b = e % nF;
-        if (a == nF) L[C_PW + ldp * a + b] = L[P_QV + idx[b]];
-        else if (b <= a) L[C_PW + ldp * a + b] = L[C_P + 32 * idx[a] + idx[b]];
+    if (r < nF) {
+        const int ia = idx[r];
+        for (int b = half; b <= r; b += 2) L[C_PW + ldp * r + b] = L[C_P + 32 * ia + idx[b]];
+        if (half == 0) L[C_PW + ldp * nF + r] = L[P_QV + ia];
     }
     if (nF > 0) {
-        bad = chol_aug(L + C_PW, ldp, nF, 1);
-        chol_back(L + C_PW, ldp, nF, 1);
-    } else WSYNC();
-    double zj = 0.0, lj = 0.0;
-    if (lane < 32) {
-        if ((F >> lane) & 1u) zj = L[C_PW + ldp * nF + __popc(F & ((1u << lane) - 1u))];
-        else {
-            double s = 0.0;
-            for (int b = 0; b < nF; b++) s += L[C_P + 32 * lane + idx[b]] * L[C_PW + ldp * nF + b];
-            lj = s - L[P_QV + lane];
-        }
+        bad = ldl_aug(L + C_PW, ldp, nF, 1);
+        ldl_back(L + C_PW, ldp, nF, 1);
     }
-    *z_out = zj; *lam_out = lj;
+    const double zj = inF ? L[C_PW + ldp * nF + pos] : 0.0;         // both half-waves hold z_(lane&31)
+    WSYNC();
+    if (lane < 32) L[P_CC + lane] = zj;
+    WSYNC();
+    double s = 0.0;
+    {
+        const double *Pr = L + C_P + 32 * r + 16 * half, *cc = L + P_CC + 16 * half;
+#pragma unroll
+        for (int b = 0; b < 16; b++) s += Pr[b] * cc[b];
+    }
+    s += __shfl_xor(s, 32, 64);
+    *z_out = (lane < 32) ? zj : 0.0;
+    *lam_out = (lane < 32 && !inF) ? s - L[P_QV + r] : 0.0;
     return bad;
 }
 
@@ -846,66 +863,73 @@ __device__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsign
 }
 
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
-__device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out)
+__device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
 {
     const int lane = LANE;
     int flags = 0;
     // ---- rows of U = [AG ; J] with weights Om, skipping zero-weight rows
     const int r0 = (P.w_com_ang == 0.0) ? 3 : 0;
     const int nU = 18 - r0;
+    const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
     for (int e = lane; e < nU * 30; e += 64) {
         const int r = r0 + e / 30, c = e % 30;
         L[B_U + e] = (r < 6) ? L[P_AG + 30 * r + c] : jdense(L, r - 6, c);
+    }
+    if (lane < nU) {                                               // Om_r * beta_r  and  1 / Om_r
+        const int rr = r0 + lane;
+        const double om = (rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot;
+        const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
+        L[B_OB + lane] = om * beta;
+        L[B_OB + 18 + lane] = 1.0 / om;
     }
     WSYNC();
     // ---- bp = D^-1 [g_a | Mb'] ; g_a = U' Om beta - D qref   (controller.cpp:127-132)
     for (int e = lane; e < 210; e += 64) {
         const int i = e / 7, cidx = e % 7;
-        const double Di = (i < 3) ? P.w_base_pos : (i < 6) ? P.w_base_ang : P.w_joints;
+        const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
         double val;
         if (cidx == 0) {
             double s = 0.0;
-            for (int r = 0; r < nU; r++) {
-                const int rr = r0 + r;
-                const double om = (rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot;
-                const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
-                s += L[B_U + 30 * r + i] * (om * beta);
-            }
-            val = s / Di - L[P_QREF + i];
-        } else val = L[P_MTOP + 30 * (cidx - 1) + i] / Di;
+            for (int r = 0; r < nU; r++) s += L[B_U + 30 * r + i] * L[B_OB + r];
+            val = s * iDi - L[P_QREF + i];
+        } else val = L[P_MTOP + 30 * (cidx - 1) + i] * iDi;
         L[B_BP + e] = val;
     }
     // ---- Cm = Om^-1 + U D^-1 U' (lower)
     const int ld = 19;
-    for (int e = lane; e < nU * nU; e += 64) {
-        const int r = e / nU, c = e % nU;
-        if (c <= r) {
-            double s = 0.0;
-            for (int i = 0; i < 30; i++) {
-                const double Di = (i < 3) ? P.w_base_pos : (i < 6) ? P.w_base_ang : P.w_joints;
-                s += L[B_U + 30 * r + i] * L[B_U + 30 * c + i] / Di;
-            }
-            if (r == c) { const int rr = r0 + r; s += 1.0 / ((rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot); }
-            L[B_K + ld * r + c] = s;
+    for (int e = lane; e < 18 * 18; e += 64) {
+        const int r = e / 18, c = e % 18;
+        if (c <= r && r < nU) {
+            const double *Ur = L + B_U + 30 * r, *Uc = L + B_U + 30 * c;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int i = 0; i < 3; i++) s0 += Ur[i] * Uc[i];
+            for (int i = 3; i < 6; i++) s1 += Ur[i] * Uc[i];
+            for (int i = 6; i < 30; i++) s2 += Ur[i] * Uc[i];
+            double sum = s0 * idp + s1 * ida + s2 * idj;
+            if (r == c) sum += L[B_OB + 18 + r];
+            L[B_K + ld * r + c] = sum;
         }
     }
     WSYNC();
-    for (int e = lane; e < 7 * nU; e += 64) {                      // V' rows: (U bp)'
-        const int cidx = e / nU, r = e % nU;
-        double s = 0.0;
-        for (int i = 0; i < 30; i++) s += L[B_U + 30 * r + i] * L[B_BP + 7 * i + cidx];
-        L[B_K + ld * (nU + cidx) + r] = s;
+    for (int e = lane; e < 7 * 18; e += 64) {                      // V' rows: (U bp)'
+        const int cidx = e / 18, r = e % 18;
+        if (r < nU) {
+            double s = 0.0;
+            for (int i = 0; i < 30; i++) s += L[B_U + 30 * r + i] * L[B_BP + 7 * i + cidx];
+            L[B_K + ld * (nU + cidx) + r] = s;
+        }
     }
-    if (chol_aug(L + B_K, ld, nU, 7)) flags |= LMH_FLAG_NOT_SPD;
-    chol_back(L + B_K, ld, nU, 7);
+    if (ldl_aug(L + B_K, ld, nU, 7)) flags |= LMH_FLAG_NOT_SPD;
+    ldl_back(L + B_K, ld, nU, 7);
     for (int e = lane; e < 210; e += 64) {                         // Y = bp - D^-1 U' t
         const int i = e / 7, cidx = e % 7;
-        const double Di = (i < 3) ? P.w_base_pos : (i < 6) ? P.w_base_ang : P.w_joints;
+        const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
         double s = 0.0;
         for (int r = 0; r < nU; r++) s += L[B_U + 30 * r + i] * L[B_K + ld * (nU + cidx) + r];
-        L[P_Y + e] = L[B_BP + e] - s / Di;
+        L[P_Y + e] = L[B_BP + e] - s * iDi;
     }
     WSYNC();
+    if (dbgp && LANE == 0) dbgp[4010] = (double)clock64();
     // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g ; Si = S^-1 via Cholesky with identity rows
     if (lane < 42) {
         const int r = lane / 7, cidx = lane % 7;
@@ -915,8 +939,8 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
         else L[B_S + 7 * r + (cidx - 1)] = s;
     }
     if (lane >= 42 && lane < 64) { for (int e = lane - 42; e < 36; e += 22) L[B_S + 7 * (6 + e / 6) + e % 6] = (e / 6 == e % 6) ? 1.0 : 0.0; }
-    if (chol_aug(L + B_S, 7, 6, 6)) flags |= LMH_FLAG_NOT_SPD;
-    chol_back(L + B_S, 7, 6, 6);
+    if (ldl_aug(L + B_S, 7, 6, 6)) flags |= LMH_FLAG_NOT_SPD;
+    ldl_back(L + B_S, 7, 6, 6);
     if (lane < 36) L[P_SI + lane] = L[B_S + 7 * (6 + lane / 6) + lane % 6];   // row r = S^-1 e_r (symmetric)
     WSYNC();
     // ---- T1 = Jb Si (12x6), W = I + T1 Jb', h = T1 d
@@ -941,6 +965,7 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
         }
     }
     WSYNC();
+    if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
     // ---- cone QP data: WG = W G, Pm = G' WG + eps I, qv = G' h   (G columns: [n; f] of foot j/16)
     for (int e = lane; e < 384; e += 64) {
         const int r = e / 32, j = e % 32, o = 6 * (j / 16);
@@ -962,6 +987,7 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
         L[C_P + e] = s;
     }
     WSYNC();
+    if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
     // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
     unsigned forced = 0u;
     if (ph == LMH_PHASE_LEFT || ph == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;    // right foot carries no force
@@ -972,6 +998,7 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
     WSYNC();
     *Fmask_io = F;
     *iters_out = it;
+    if (dbgp && LANE == 0) dbgp[4013] = (double)clock64();
     // ---- recover w = G c, lam = -Si (Jb' w - d), a = -(Y_g + Y_M lam)
     if (lane < 12) {
         const int ft = lane / 6, k = lane % 6;
@@ -1005,7 +1032,7 @@ __device__ void phase_outputs(double *L)
 {
     const int lane = LANE;
     if (lane < 24) {
-        const int a = lane, st = c_jstart[a], ft = (a < 6) ? 0 : (a < 12) ? 1 : -1;
+        const int a = lane, st = f_jstart(a), ft = (a < 6) ? 0 : (a < 12) ? 1 : -1;
         const int nl = (a < 12) ? 6 : (a < 22) ? 5 : 2;
         double s = 0.0;
         for (int c = 0; c < 6; c++) s += L[P_MTOP + 30 * c + 6 + a] * L[P_A + c];
@@ -1037,19 +1064,31 @@ __device__ void phase_outputs(double *L)
 __device__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
 {
     int flags = 0, ph = 0;
+    // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
+#define STAMP(i) do { if (dbg && LANE == 0) dbg[4000 + (i)] = (double)clock64(); } while (0)
+    STAMP(0);
     phase_fk(L);
+    STAMP(1);
     phase_com_x(L);
+    STAMP(2);
     if (dbg) {
         for (int e = LANE; e < 336; e += 64) dbg[e] = L[A_T + e];
         for (int e = LANE; e < 252; e += 64) { dbg[336 + e] = L[A_XE + e]; dbg[672 + e] = L[A_XB + e]; }
         for (int e = LANE; e < 84; e += 64) dbg[588 + e] = L[A_XP + e];
     }
+    STAMP(3);
     phase_newton_euler(L);
+    STAMP(4);
     phase_crba(L);
+    STAMP(5);
     phase_jacobian(L);
+    STAMP(6);
     flags |= phase_refs(L, P, inst, t, k_out, &ph);
-    flags |= phase_qp(L, P, ph, Fmask, iters_out);
+    STAMP(7);
+    flags |= phase_qp(L, P, ph, Fmask, iters_out, dbg);
+    STAMP(8);
     phase_outputs(L);
+    STAMP(9);
     if (dbg) {
         const int lane = LANE;
         for (int e = lane; e < 30; e += 64) { dbg[924 + e] = L[P_C + e]; dbg[1643 + e] = L[P_QREF + e]; dbg[3181 + e] = L[P_A + e]; }
@@ -1072,11 +1111,22 @@ __device__ int controller_eval(double *L, const LmhDevParams &P, int inst, doubl
     return flags;
 }
 
+__device__ void load_tables(double *L)
+{
+    for (int e = LANE; e < 160; e += 64) {
+        double v;
+        if (e < 25) v = c_dh_r[e]; else if (e < 50) v = c_dh_d[e - 25]; else if (e < 75) v = c_dh_ca[e - 50];
+        else if (e < 100) v = c_dh_sa[e - 75]; else if (e < 124) v = c_dh_off[e - 100]; else v = c_aux[(e - 124) / 12][(e - 124) % 12];
+        L[P_TAB + e] = v;
+    }
+}
 __device__ void load_common(double *L, const LmhDevParams &P, int inst)
 {
     const double *mo = P.model + (size_t)P.model_stride * inst;
     for (int e = LANE; e < 393; e += 64) L[P_MODEL + e] = mo[e];
     for (int e = LANE; e < 192; e += 64) L[P_GCOL + e] = P.gcol[e];
+    load_tables(L);
+    WSYNC();
 }
 
 __device__ void store_out(const double *L, double *out)
@@ -1193,6 +1243,7 @@ __global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double
     const int lane = LANE;
     const double *rw = raw + (size_t)mi * 28 * LMH_LINK_STRIDE;
     for (int e = lane; e < 30; e += 64) L[P_Q + e] = 0.0;          // FK at q = 0
+    load_tables(L);
     WSYNC();
     phase_fk(L);
     double mloc = 0.0;
@@ -1354,9 +1405,9 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
                     else { x0 = d1; x1 = -d0; x2 = 0; }
                 } else {
                     // joint (lane-6) contributes if its frame is on the path from frame i to the base
-                    const int jf = c_jframe[lane - 6];
+                    const int jf = f_jframe(lane - 6);
                     int j = i; bool on = false;
-                    while (j != 0) { if (j == jf) { on = true; break; } j = c_parent[j]; }
+                    while (j != 0) { if (j == jf) { on = true; break; } j = f_parent(j); }
                     if (on) {
                         const double *Tj = L + A_T + 12 * jf;
                         const double z0 = Tj[2], z1 = Tj[6], z2 = Tj[10];

@@ -1,0 +1,29 @@
+"""Diagnostic: per-phase cycle stamps (s_memtime) of one controller evaluation, debug kernel."""
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+import numpy as np, torch, json
+from linearmpchumanoid_amd.controller import BatchedController, default_config
+from helpers import perturbed_velocities
+ik = json.load(open('tests/golden/ik_posture.json'))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ctl = BatchedController(B, default_config(dt=1e-3, time_horizon=0.016, z_com=ik['z_com'], warm_start=warm))
+ctl.set_refs_stance(2.0, 2)
+v = perturbed_velocities(B)
+st = ctl.new_state(np.array(ik['q']), v, t=0.0)
+for rep in range(3):
+    out, status, dbg = ctl.stand_step(st, debug=True)
+torch.cuda.synchronize()
+d = dbg.cpu().numpy(); s = status.cpu().numpy()
+names = ['fk', 'com_x', 'dump', 'newton_euler', 'crba', 'jacobian', 'refs', 'qp', 'outputs']
+st_ = d[:, 4000:4010]
+dur = np.diff(st_, axis=1)
+print("instances", B, "warm", warm, "mean qp iters", s[:, 1].mean(), "max", s[:, 1].max())
+tot = (st_[:, 9] - st_[:, 0])
+print("total cycles/eval: mean %.0f  p50 %.0f  max %.0f" % (tot.mean(), np.median(tot), tot.max()))
+for n, c in zip(names, dur.mean(axis=0)):
+    print("  %-14s %8.0f cycles  %5.1f%%" % (n, c, 100 * c / tot.mean()))
+q = d[:, 4010:4014]
+sub = np.stack([q[:, 0] - st_[:, 7], q[:, 1] - q[:, 0], q[:, 2] - q[:, 1], q[:, 3] - q[:, 2], st_[:, 8] - q[:, 3]], axis=1).mean(axis=0)
+for n, c in zip(['qp:woodbury', 'qp:schur+W', 'qp:WG,P', 'qp:cone solve', 'qp:recover'], sub):
+    print("  %-14s %8.0f cycles  %5.1f%%" % (n, c, 100 * c / tot.mean()))
