@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../include/lmh.h"
@@ -126,14 +127,14 @@ static int build_gain_row(const lmh_config &c, double zcom, int N, double *rec)
 
 // friction-cone generators: column j = 16 foot + 4 vertex + edge  ->  [p_v x ray_e ; ray_e]
 // (src/controller.cpp:33-36,185-270, vertices src/Robot.cpp:38-42; same for both feet)
-static void build_gcol(double mu, double *g /*[32][6]*/)
+static void build_gcol(double mu, double *g /*[16][6] (one foot; both feet are identical) | (G G')^-1 [6][6] | G'(G G')^-1 [16][6]*/)
 {
     const double ray[4][3] = {{mu, 0, 1}, {0, mu, 1}, {-mu, 0, 1}, {0, -mu, 1}};
     const double vtx[4][3] = {{0.1, 0.025, 0}, {0.1, -0.025, 0}, {-0.05, 0.025, 0}, {-0.05, -0.025, 0}};
-    for (int ft = 0; ft < 2; ft++)
+    {
         for (int v = 0; v < 4; v++)
             for (int e = 0; e < 4; e++) {
-                double *o = g + 6 * (16 * ft + 4 * v + e);
+                double *o = g + 6 * (4 * v + e);
                 const double *p = vtx[v], *r = ray[e];
                 // crossMatrix(p) * ray, term by term as the dense product does
                 o[0] = 0 * r[0] + (-p[2]) * r[1] + p[1] * r[2];
@@ -141,6 +142,32 @@ static void build_gcol(double mu, double *g /*[32][6]*/)
                 o[2] = (-p[1]) * r[0] + p[0] * r[1] + 0 * r[2];
                 o[3] = r[0]; o[4] = r[1]; o[5] = r[2];
             }
+    }
+    // Gamma = G_f G_f' (6x6, identical for both feet), its inverse and the min-norm map G_f' Gamma^-1
+    double Gm[36] = {0}, A[6][12];
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++)
+            for (int j = 0; j < 16; j++) Gm[6 * a + b] += g[6 * j + a] * g[6 * j + b];
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 12; b++) A[a][b] = (b < 6) ? Gm[6 * a + b] : ((b - 6 == a) ? 1.0 : 0.0);
+    for (int c = 0; c < 6; c++) {                                   // Gauss-Jordan with partial pivoting
+        int pv = c;
+        for (int rr = c + 1; rr < 6; rr++) if (std::fabs(A[rr][c]) > std::fabs(A[pv][c])) pv = rr;
+        for (int b = 0; b < 12; b++) std::swap(A[c][b], A[pv][b]);
+        const double d = A[c][c];
+        for (int b = 0; b < 12; b++) A[c][b] /= d;
+        for (int rr = 0; rr < 6; rr++)
+            if (rr != c) { const double f = A[rr][c]; for (int b = 0; b < 12; b++) A[rr][b] -= f * A[c][b]; }
+    }
+    double *gi = g + 96, *gp = g + 96 + 36;
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) gi[6 * a + b] = 0.5 * (A[a][6 + b] + A[b][6 + a]);
+    for (int j = 0; j < 16; j++)
+        for (int b = 0; b < 6; b++) {
+            double sacc = 0;
+            for (int a = 0; a < 6; a++) sacc += g[6 * j + a] * gi[6 * a + b];
+            gp[6 * j + b] = sacc;
+        }
 }
 
 static void fill_params(lmh_handle *h)
@@ -188,7 +215,7 @@ extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lm
     h->N = (int)(cfg->time_horizon / cfg->dt);                      // mpcLinearPendulum.cpp:43
     if (h->N < 1 || h->N > LMH_MAX_HORIZON) { delete h; return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/dt must be in [1, 64]"); }
     std::memset(&h->P, 0, sizeof(h->P));
-    double g[32 * 6];
+    double g[16 * 6 + 36 + 96];
     build_gcol(cfg->mu, g);
     HIPCHK(hipMalloc(&h->d_gcol, sizeof(g)));
     HIPCHK(hipMemcpy(h->d_gcol, g, sizeof(g), hipMemcpyHostToDevice));

@@ -95,10 +95,15 @@ enum {
     P_MTOP = 744, P_HL = 924, P_JC = 1068, P_AG = 1212,
     P_QREF = 1392, P_HREF = 1422, P_FREF = 1428, P_VFOOT = 1440,
     P_Y = 1452,       // 30 x 7 : H^-1 [g | Mb']
-    P_SI = 1662, P_D6 = 1698, P_W = 1704, P_H12 = 1848, P_QV = 1860, P_CC = 1892, P_LAM = 1924,
-    P_W12 = 1956, P_LAM6 = 1968, P_A = 1974, P_GCOL = 2004, P_TAU = 2196, P_QDD = 2220,
-    P_TAB = 2252,     // DH r|d|cos a|sin a (4x25), theta offsets (24), fixed transforms (36)
-    P_END = 2412,
+    P_SI = 1662, P_D6 = 1698, P_W = 1704, P_H12 = 1848, P_QV = 1860, P_CC = 1892, P_U12 = 1924,
+    P_W12 = 1956, P_LAM6 = 1968, P_A = 1974,
+    P_GCOL = 2004,    // friction-cone generators of ONE foot (16 x 6; both feet share vertices and rays)
+    P_GI6 = 2100,     // (G_f G_f')^-1 (6x6)
+    P_GPI = 2136,     // G_f' (G_f G_f')^-1 (16x6): min-norm coefficients of a foot wrench
+    P_TAU = 2232, P_QDD = 2256,
+    P_TAB = 2286,     // DH r|d|cos a|sin a (4x25), theta offsets (24), fixed transforms (36)
+    P_POLY = 2446,    // foot polynomials: rF[3][8] | lF[3][8] | counts (6, stored as doubles)
+    P_END = 2504,
     // ---- scratch, phase A1 (kinematics + Newton-Euler)
     S0 = P_END,
     A_LC = S0 + 0,    // 28 x 12 local transforms (dead after FK)
@@ -118,11 +123,11 @@ enum {
     B_S = S0 + 1226,  // 12 x 7
     B_T1 = S0 + 1310, // 12 x 6
     B_OB = S0 + 1382, // Om*beta (18) | 1/Om (18)
+    B_LS = S0 + 1420, // 18 x 19 rows of L
     // ---- phase C (cone QP)
     C_WG = S0 + 0,    // 12 x 32
-    C_P = S0 + 384,   // 32 x 32
-    C_PW = S0 + 1408, // 34 x 33
-    C_IDX = S0 + 2530,
+    C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
+    C_LS = S0 + 1440, // 32 x 33 rows of L for the backward substitution
     LDS_DOUBLES = S0 + 2548
 };
 
@@ -170,51 +175,60 @@ __device__ __forceinline__ double fast_rcp(double d)
     return y;
 }
 
-// In-place LDL' of the leading n x n block of K (lower triangle, row stride ld) carrying m extra
-// rows n..n+m-1 along (n + m <= 33).  On exit K[j][j] = d_j, K[i][j] = L_ij (unit lower) and extra
-// row n+r holds D^-1 L^-1 v_r.  Lane map: row = pivot+1+(lane&31), the two half-waves split the
-// columns by parity -- no integer division, one wave fence per pivot.  Returns non-zero (wave-uniform)
-// if a pivot was not positive.  n, m wave-uniform.
-__device__ int ldl_aug(double *K, int ld, int n, int m)
+__device__ __forceinline__ double bcast_lane(double x, int l)     // l is a compile-time constant after unrolling
 {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Register-resident LDL' solve of an SPD system with M right-hand sides, N <= 32.
+// Lane i < N holds row i of the matrix in a[] (entries a[c], c <= i, are used; rows / columns whose
+// bit is clear in `live` must be zero and are skipped) and its rhs entries in b[].  The pivot column
+// is broadcast with v_readlane (no LDS round trip inside the factorisation); the rows of L are parked
+// once in Ls (row stride N+1, conflict free) for the backward substitution.  On exit b[r] of lane i
+// holds x_i.  Returns non-zero (wave-uniform) if a pivot was not positive.
+template <int N, int M>
+__device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], unsigned live, double *Ls)
+{
+    const int lane = LANE;
     int bad = 0;
-    const int rows = n + m, r = LANE & 31, half = LANE >> 5;
-    for (int j = 0; j < n; j++) {
-        WSYNC();
-        const double d = K[j * ld + j];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (!((live >> j) & 1u)) continue;                        // wave-uniform
+        const double d = bcast_lane(a[j], j);
         if (!(d > 0.0)) bad = 1;
         const double invd = fast_rcp(d);
-        const int i = j + 1 + r;
-        double f = 0.0;
-        if (i < rows) {
-            f = K[i * ld + j] * invd;
-            const int cend = (i < n) ? i : n - 1;
-            double *Ki = K + i * ld;
-            for (int c = j + 1 + half; c <= cend; c += 2) Ki[c] -= f * K[c * ld + j];   // K[c][j] still d_j L_cj
+        const double f = a[j] * invd;                             // L_ij in lanes i > j
+#pragma unroll
+        for (int c = j + 1; c < N; c++) a[c] = fma(-f, bcast_lane(a[j], c), a[c]);   // lane c still holds d_j L_cj
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+            const double zj = bcast_lane(b[r], j);
+            b[r] = (lane > j) ? fma(-f, zj, b[r]) : ((lane == j) ? zj * invd : b[r]);
         }
-        if (i < rows && half == 0) K[i * ld + j] = f;           // after every lane's reads of column j
+        if (lane > j) a[j] = f;
     }
     WSYNC();
+    if (lane < N) {
+#pragma unroll
+        for (int c = 0; c < N - 1; c++) Ls[lane * (N + 1) + c] = a[c];              // L[lane][c], c < lane
+    }
+    WSYNC();
+#pragma unroll
+    for (int j = N - 1; j > 0; j--) {
+        if (!((live >> j) & 1u)) continue;
+        const double lji = (lane < j) ? Ls[j * (N + 1) + lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < M; r++) b[r] = fma(-lji, bcast_lane(b[r], j), b[r]);
+    }
     return bad;
-}
-// Solve L' x = w in place for the m extra rows (w = D^-1 L^-1 v from ldl_aug).
-__device__ void ldl_back(double *K, int ld, int n, int m)
-{
-    const int i = LANE & 31, half = LANE >> 5;
-    for (int j = n - 1; j > 0; j--) {
-        WSYNC();
-        if (i < j) {
-            const double lji = K[j * ld + i];
-            for (int r = half; r < m; r += 2) K[(n + r) * ld + i] -= lji * K[(n + r) * ld + j];
-        }
-    }
-    WSYNC();
 }
 
 // ============================================================================ kinematics
 // Robot::forwardKinematics + matTrans + eulerAnglesToSO3 (Robot.cpp:45-160,176-223,
 // generalizedFunctions.cpp:52-72).  Reads L[P_Q], writes A_T (30 x 3x4) and L[P_SC].
-__device__ void phase_fk(double *L)
+__device__ __forceinline__ void phase_fk(double *L)
 {
     const int lane = LANE;
     if (lane < 28) {
@@ -276,7 +290,7 @@ __device__ void phase_fk(double *L)
 
 // Robot::computeCoM (Robot.cpp:225-238) + parentTransMatrix/allVelocityMatrices/velocityMatrix
 // (Robot.cpp:276-298, generalizedFunctions.cpp:11-27: R' used as inverse, kept).
-__device__ void phase_com_x(double *L)
+__device__ __forceinline__ void phase_com_x(double *L)
 {
     const int lane = LANE;
     double cx = 0, cy = 0, cz = 0;
@@ -346,7 +360,7 @@ __device__ void phase_com_x(double *L)
 
 // Dynamics::computeC (gravity / no gravity) + computeJpqpFrame(7),(14): forward and backward
 // Newton-Euler with qdd = 0 on the STALE velocity (Dynamics.cpp:29-60,124-200).
-__device__ void phase_newton_euler(double *L)
+__device__ __forceinline__ void phase_newton_euler(double *L)
 {
     const int lane = LANE;
     // base: vel0 = vhat[0:6]; accg0 = X0 * [0 0 0 0 0 9.81]; acc00 = 0
@@ -458,7 +472,7 @@ __device__ void phase_newton_euler(double *L)
 }
 
 // Dynamics::computeM (CRBA, Dynamics.cpp:62-101) -> Mtop = [Ic0 | F2], Hl (per-limb joint blocks)
-__device__ void phase_crba(double *L)
+__device__ __forceinline__ void phase_crba(double *L)
 {
     const int lane = LANE;
     // composite inertias start as the body inertias: [Ibar, [h]x; -[h]x, m 1]   (Dynamics.cpp:4-13)
@@ -557,7 +571,7 @@ __device__ void phase_crba(double *L)
 
 // Kinematics::feetJacobian / frameJacobian (invKinematics.cpp:72-149), chain products in the
 // reference's association ((X7 X6) X5 ...); X kept as (A, B) with X = [A 0; B A].
-__device__ void phase_jacobian(double *L)
+__device__ __forceinline__ void phase_jacobian(double *L)
 {
     const int lane = LANE;
     const int foot = lane / 18, el = lane % 18, half = el / 9, r = (el % 9) / 3, c = el % 3;
@@ -608,7 +622,7 @@ __device__ __forceinline__ double jdense(const double *L, int row, int col)
 // Dynamics::centroidalMatrixAndBias (Dynamics.cpp:103-121), Robot::computeComMomentum
 // (Robot.cpp:300-310), Mpc3dLip::compute (mpcLinearPendulum.cpp:78-109), PD references
 // (controller.cpp:296-386).
-__device__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, int *k_out, int *phase_out)
+__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, int *k_out, int *phase_out)
 {
     const int lane = LANE;
     int flags = 0;
@@ -719,8 +733,8 @@ __device__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, 
     }
     if (lane >= 16 && lane < 22) {                                 // position part, polynomials (polyval/polyder)
         const int ft = (lane - 16) / 3, ax = (lane - 16) % 3;
-        const double *co = ft ? P.lF[ax] : P.rF[ax];
-        const int n = ft ? P.lFn[ax] : P.rFn[ax];
+        const double *co = L + P_POLY + 24 * ft + 8 * ax;
+        const int n = (int)L[P_POLY + 48 + 3 * ft + ax];
         double pv = 0, xp = 1;
         for (int i = 0; i < n; i++) { pv += co[i] * xp; xp *= t; }
         double vv = 0; xp = 1;
@@ -736,42 +750,34 @@ __device__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, 
 }
 
 
-// Solve P_FF z_F = qv_F on the free set F (compact LDL' in C_PW).  Returns z_j for lane j in F
-// (0 otherwise) and, for lanes j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
-__device__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
+// Solve P_FF z_F = qv_F on the free set F: rows/columns outside F are masked out of a fixed
+// 32 x 32 register-resident LDL' (their pivots are skipped).  Returns z_j for lane j in F (0 otherwise)
+// and, for lanes j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
+__device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
 {
     const int lane = LANE, r = lane & 31, half = lane >> 5;
-    int *idx = (int *)(L + C_IDX);
-    const int ldp = 33;
-    int bad = 0;
-    const int nF = __popc(F);
-    const int pos = __popc(F & ((1u << r) - 1u));
-    const bool inF = (F >> r) & 1u;
-    WSYNC();
-    if (lane < 32 && inF) idx[pos] = lane;
-    WSYNC();
-    if (r < nF) {
-        const int ia = idx[r];
-        for (int b = half; b <= r; b += 2) L[C_PW + ldp * r + b] = L[C_P + 32 * ia + idx[b]];
-        if (half == 0) L[C_PW + ldp * nF + r] = L[P_QV + ia];
+    const bool inF = (lane < 32) && ((F >> lane) & 1u);
+    double a[32], b[1];
+    {
+        const double *Pr = L + C_P + 33 * r;
+#pragma unroll
+        for (int c = 0; c < 32; c++) a[c] = (inF && ((F >> c) & 1u)) ? Pr[c] : 0.0;
+        b[0] = inF ? L[P_QV + r] : 0.0;
     }
-    if (nF > 0) {
-        bad = ldl_aug(L + C_PW, ldp, nF, 1);
-        ldl_back(L + C_PW, ldp, nF, 1);
-    }
-    const double zj = inF ? L[C_PW + ldp * nF + pos] : 0.0;         // both half-waves hold z_(lane&31)
+    const int bad = ldl_solve_regs<32, 1>(a, b, F, L + C_LS);
+    const double zj = inF ? b[0] : 0.0;
     WSYNC();
     if (lane < 32) L[P_CC + lane] = zj;
     WSYNC();
     double s = 0.0;
     {
-        const double *Pr = L + C_P + 32 * r + 16 * half, *cc = L + P_CC + 16 * half;
+        const double *Pr = L + C_P + 33 * r + 16 * half, *cc = L + P_CC + 16 * half;
 #pragma unroll
-        for (int b = 0; b < 16; b++) s += Pr[b] * cc[b];
+        for (int bq = 0; bq < 16; bq++) s += Pr[bq] * cc[bq];
     }
     s += __shfl_xor(s, 32, 64);
-    *z_out = (lane < 32) ? zj : 0.0;
-    *lam_out = (lane < 32 && !inF) ? s - L[P_QV + r] : 0.0;
+    *z_out = zj;
+    *lam_out = (lane < 32 && !((F >> lane) & 1u)) ? s - L[P_QV + r] : 0.0;
     return bad;
 }
 
@@ -779,8 +785,9 @@ __device__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_
 // minimiser is unique.  Fast path: block principal pivoting from the incoming free set (one solve when
 // the active set did not change, typically <= 8 from a cold start).  If that has not settled after
 // BPP_MAX rounds, a Lawson-Hanson active-set pass from the empty set finishes (monotone, finite).
+// One loop, one call site of the (large, fully unrolled) free-set solve.
 #define BPP_MAX 10
-__device__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters)
+__device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters, double *dbgp = nullptr)
 {
     const int lane = LANE;
     int flags = 0, it = 0;
@@ -790,52 +797,83 @@ __device__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsign
     const double toll = 1e-12 * (1.0 + qmax);                    // ~100x the round-off of (P c - q)
     const bool mine = (lane < 32) && !((forced >> lane) & 1u);
     int ninf = 33, budget = 3;
-    bool done = false;
+    bool lh = false;                                               // false: block pivoting, true: Lawson-Hanson
     double cj = 0.0, lj = 0.0;
-    while (it < BPP_MAX) {
+    if (forced == 0u && F == 0xFFFFFFFFu) {
+        // every coefficient free (the usual balance case): then w = G c solves the 12 x 12 SPD system
+        // (W + eps (G G')^-1) w = h and c = G'(G G')^-1 w  (push-through identity; G G' is constant,
+        // block diagonal and well conditioned) -- 12 pivots instead of 32.
         it++;
-        if (solve_free_set(L, F, &cj, &lj)) flags |= LMH_FLAG_NOT_SPD;
-        const double cmax = wave_max(fabs(cj));
-        const double tolc = 1e-10 * (1.0 + cmax);
-        const bool isbad = mine && ((((F >> lane) & 1u) && cj < -tolc) || (!((F >> lane) & 1u) && lj < -toll));
-        const unsigned bad = (unsigned)__ballot(isbad);
-        if (bad == 0u) { done = true; break; }
-        const int nb = __popc(bad);
-        if (nb < ninf) { ninf = nb; budget = 3; F ^= bad; }
-        else if (budget > 0) { budget--; F ^= bad; }
-        else F ^= (1u << (31 - __clz((int)bad)));                  // Murty: flip the highest-index violator only
-    }
-    if (!done) {
-        // ---- Lawson-Hanson from the empty free set (c = 0 is feasible)
-        F = 0u; cj = 0.0;
-        for (;;) {
-            // w = qv - P c on the active set; pick the most violated multiplier
-            int *idx = (int *)(L + C_IDX);
+        double a[12], b[1];
+        {
+            const int fi = lane / 6, ri = lane % 6;
+#pragma unroll
+            for (int c = 0; c < 12; c++) {
+                double v = 0.0;
+                if (lane < 12 && c <= lane) {
+                    v = L[P_W + 12 * lane + c];
+                    if (c / 6 == fi) v += P.eps_coeff * L[P_GI6 + 6 * ri + c % 6];
+                }
+                a[c] = v;
+            }
+            b[0] = (lane < 12) ? L[P_H12 + lane] : 0.0;
+        }
+        if (ldl_solve_regs<12, 1>(a, b, 0xFFFu, L + C_LS)) flags |= LMH_FLAG_NOT_SPD;
+        WSYNC();
+        if (lane < 12) L[P_U12 + lane] = b[0];
+        WSYNC();
+        double zj = 0.0;
+        if (lane < 32) {
+            const double *gp = L + P_GPI + 6 * (lane & 15), *u = L + P_U12 + 6 * (lane >> 4);
+#pragma unroll
+            for (int k = 0; k < 6; k++) zj += gp[k] * u[k];
+        }
+        const double cmax = wave_max(fabs(zj));
+        const unsigned bad = (unsigned)__ballot(lane < 32 && zj < -1e-10 * (1.0 + cmax));
+        cj = zj;
+        if (bad == 0u) {
             WSYNC();
             if (lane < 32) L[P_CC + lane] = cj;
             WSYNC();
-            double wj = -1.0e300;
-            if (mine && !((F >> lane) & 1u)) {
-                double s = 0.0;
-                for (int b = 0; b < 32; b++) s += L[C_P + 32 * lane + b] * L[P_CC + b];
-                wj = L[P_QV + lane] - s;
-            }
-            double best = wj; int bi = lane;
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (!(best > toll)) break;                             // dual feasible: optimal
-            if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
-            F |= (1u << bi);
-            for (;;) {                                             // inner loop: keep c >= 0
-                it++;
-                double zj, dummy;
-                if (solve_free_set(L, F, &zj, &dummy)) flags |= LMH_FLAG_NOT_SPD;
-                const bool inF = (lane < 32) && ((F >> lane) & 1u);
-                const bool neg = inF && !(zj > 0.0);
-                const unsigned negm = (unsigned)__ballot(neg);
-                if (negm == 0u) { cj = inF ? zj : 0.0; break; }
+            *F_io = F; *iters = it;
+            return flags;
+        }
+        ninf = __popc(bad);
+        F ^= bad;
+    }
+    for (;;) {
+        it++;
+        double zj;
+        if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
+        if (solve_free_set(L, F, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+        if (dbgp && lane == 0 && it <= 12) { dbgp[4021 + 2 * it] = (double)clock64(); dbgp[4050 + it] = (double)__popc(F); }
+        const bool inF = (lane < 32) && ((F >> lane) & 1u);
+        if (!lh) {
+            const double cmax = wave_max(fabs(zj));
+            const double tolc = 1e-10 * (1.0 + cmax);
+            const bool isbad = mine && ((inF && zj < -tolc) || (!inF && lj < -toll));
+            const unsigned bad = (unsigned)__ballot(isbad);
+            cj = zj;
+            if (bad == 0u) break;
+            if (it >= BPP_MAX) { lh = true; F = 0u; cj = 0.0; continue; }    // next solve: F empty, lam = -qv
+            const int nb = __popc(bad);
+            if (nb < ninf) { ninf = nb; budget = 3; F ^= bad; }
+            else if (budget > 0) { budget--; F ^= bad; }
+            else F ^= (1u << (31 - __clz((int)bad)));              // Murty: flip the highest-index violator only
+        } else {
+            const bool neg = inF && !(zj > 0.0);
+            const unsigned negm = (unsigned)__ballot(neg);
+            if (negm == 0u) {
+                cj = inF ? zj : 0.0;                               // accept, then test dual feasibility
+                double best = (mine && !inF) ? -lj : -1.0e300;
+                int bi = lane;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (!(best > toll)) break;                         // optimal
+                F |= (1u << bi);
+            } else {                                               // step towards z until a coefficient hits zero
                 double al = neg ? ((cj - zj > 0.0) ? cj / (cj - zj) : 0.0) : 1.0e300;
                 double amin = al; int ai = lane;
                 for (int o = 32; o > 0; o >>= 1) {
@@ -847,15 +885,12 @@ __device__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsign
                 const unsigned dm = (unsigned)__ballot(drop);
                 if (drop) cj = 0.0;
                 F &= ~dm;
-                if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
             }
-            if (flags & LMH_FLAG_QP_MAXITER) break;
-            (void)idx;
         }
-        lj = 0.0;
+        if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
     }
     WSYNC();
-    if (lane < 32) { L[P_CC + lane] = ((F >> lane) & 1u) ? cj : 0.0; L[P_LAM + lane] = lj; }
+    if (lane < 32) L[P_CC + lane] = ((F >> lane) & 1u) ? cj : 0.0;
     WSYNC();
     *F_io = F;
     *iters = it;
@@ -863,7 +898,7 @@ __device__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsign
 }
 
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
-__device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
+__device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
 {
     const int lane = LANE;
     int flags = 0;
@@ -919,8 +954,21 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
             L[B_K + ld * (nU + cidx) + r] = s;
         }
     }
-    if (ldl_aug(L + B_K, ld, nU, 7)) flags |= LMH_FLAG_NOT_SPD;
-    ldl_back(L + B_K, ld, nU, 7);
+    WSYNC();
+    {   // Cm t = V for the 7 right-hand sides: row-per-lane register LDL'
+        double a[18], bb[7];
+        const bool on = lane < nU;
+#pragma unroll
+        for (int c = 0; c < 18; c++) a[c] = (on && c <= lane) ? L[B_K + ld * lane + c] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 7; r++) bb[r] = on ? L[B_K + ld * (nU + r) + lane] : 0.0;
+        if (ldl_solve_regs<18, 7>(a, bb, (1u << nU) - 1u, L + B_LS)) flags |= LMH_FLAG_NOT_SPD;
+        if (on) {
+#pragma unroll
+            for (int r = 0; r < 7; r++) L[B_K + ld * (nU + r) + lane] = bb[r];
+        }
+    }
+    WSYNC();
     for (int e = lane; e < 210; e += 64) {                         // Y = bp - D^-1 U' t
         const int i = e / 7, cidx = e % 7;
         const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
@@ -938,10 +986,17 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
         if (cidx == 0) L[P_D6 + r] = L[P_C + r] - s;
         else L[B_S + 7 * r + (cidx - 1)] = s;
     }
-    if (lane >= 42 && lane < 64) { for (int e = lane - 42; e < 36; e += 22) L[B_S + 7 * (6 + e / 6) + e % 6] = (e / 6 == e % 6) ? 1.0 : 0.0; }
-    if (ldl_aug(L + B_S, 7, 6, 6)) flags |= LMH_FLAG_NOT_SPD;
-    ldl_back(L + B_S, 7, 6, 6);
-    if (lane < 36) L[P_SI + lane] = L[B_S + 7 * (6 + lane / 6) + lane % 6];   // row r = S^-1 e_r (symmetric)
+    WSYNC();
+    {   // Si = S^-1: six unit right-hand sides
+        double a[6], bb[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) { a[c] = (lane < 6 && c <= lane) ? L[B_S + 7 * lane + c] : 0.0; bb[c] = (lane == c) ? 1.0 : 0.0; }
+        if (ldl_solve_regs<6, 6>(a, bb, 0x3Fu, L + B_LS)) flags |= LMH_FLAG_NOT_SPD;
+        if (lane < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) L[P_SI + 6 * lane + c] = bb[c];
+        }
+    }
     WSYNC();
     // ---- T1 = Jb Si (12x6), W = I + T1 Jb', h = T1 d
     for (int e = lane; e < 72; e += 64) {
@@ -970,21 +1025,21 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
     for (int e = lane; e < 384; e += 64) {
         const int r = e / 32, j = e % 32, o = 6 * (j / 16);
         double s = 0.0;
-        for (int k = 0; k < 6; k++) s += L[P_W + 12 * r + o + k] * L[P_GCOL + 6 * j + k];
+        for (int k = 0; k < 6; k++) s += L[P_W + 12 * r + o + k] * L[P_GCOL + 6 * (j & 15) + k];
         L[C_WG + e] = s;
     }
     if (lane < 32) {
         const int o = 6 * (lane / 16);
         double s = 0.0;
-        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * lane + k] * L[P_H12 + o + k];
+        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
         L[P_QV + lane] = s;
     }
     WSYNC();
     for (int e = lane; e < 1024; e += 64) {
         const int i = e / 32, j = e % 32, o = 6 * (i / 16);
         double s = (i == j) ? P.eps_coeff : 0.0;
-        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * i + k] * L[C_WG + 32 * (o + k) + j];
-        L[C_P + e] = s;
+        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * (i & 15) + k] * L[C_WG + 32 * (o + k) + j];
+        L[C_P + 33 * i + j] = s;
     }
     WSYNC();
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
@@ -994,7 +1049,7 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
     if (ph == LMH_PHASE_RIGHT || ph == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
     unsigned F = (P.warm_start ? *Fmask_io : 0xFFFFFFFFu) & ~forced;
     int it = 0;
-    flags |= cone_qp(L, P, forced, &F, &it);
+    flags |= cone_qp(L, P, forced, &F, &it, dbgp);
     WSYNC();
     *Fmask_io = F;
     *iters_out = it;
@@ -1003,7 +1058,7 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
     if (lane < 12) {
         const int ft = lane / 6, k = lane % 6;
         double s = 0.0;
-        for (int j = 0; j < 16; j++) s += L[P_GCOL + 6 * (16 * ft + j) + k] * L[P_CC + 16 * ft + j];
+        for (int j = 0; j < 16; j++) s += L[P_GCOL + 6 * j + k] * L[P_CC + 16 * ft + j];
         L[P_W12 + lane] = s;
     }
     WSYNC();
@@ -1028,7 +1083,7 @@ __device__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmas
 }
 
 // Controller::WBC tail (controller.cpp:134-153): tau, base acceleration back to the world frame.
-__device__ void phase_outputs(double *L)
+__device__ __forceinline__ void phase_outputs(double *L)
 {
     const int lane = LANE;
     if (lane < 24) {
@@ -1061,7 +1116,7 @@ __device__ void phase_outputs(double *L)
 }
 
 // one controller evaluation on the state in L[P_Q], L[P_V], L[P_VP] at time t
-__device__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
+__device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
 {
     int flags = 0, ph = 0;
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
@@ -1100,7 +1155,7 @@ __device__ int controller_eval(double *L, const LmhDevParams &P, int inst, doubl
         for (int e = lane; e < 8; e += 64) dbg[1635 + e] = L[P_MPC + e];
         for (int e = lane; e < 210; e += 64) dbg[1691 + e] = L[P_Y + e];
         for (int e = lane; e < 36; e += 64) dbg[1901 + e] = L[P_SI + e];
-        for (int e = lane; e < 1024; e += 64) dbg[2093 + e] = L[C_P + e];
+        for (int e = lane; e < 1024; e += 64) dbg[2093 + e] = L[C_P + 33 * (e / 32) + e % 32];
         for (int e = lane; e < 32; e += 64) { dbg[3117 + e] = L[P_QV + e]; dbg[3149 + e] = L[P_CC + e]; }
     }
     // non-finite guard (reference aborts on NaN/Inf, controller.cpp:448-466)
@@ -1111,7 +1166,7 @@ __device__ int controller_eval(double *L, const LmhDevParams &P, int inst, doubl
     return flags;
 }
 
-__device__ void load_tables(double *L)
+__device__ __forceinline__ void load_tables(double *L)
 {
     for (int e = LANE; e < 160; e += 64) {
         double v;
@@ -1120,16 +1175,33 @@ __device__ void load_tables(double *L)
         L[P_TAB + e] = v;
     }
 }
-__device__ void load_common(double *L, const LmhDevParams &P, int inst)
+__device__ __forceinline__ void load_common(double *L, const LmhDevParams &P, int inst)
 {
     const double *mo = P.model + (size_t)P.model_stride * inst;
     for (int e = LANE; e < 393; e += 64) L[P_MODEL + e] = mo[e];
-    for (int e = LANE; e < 192; e += 64) L[P_GCOL + e] = P.gcol[e];
+    for (int e = LANE; e < 228; e += 64) L[P_GCOL + e] = P.gcol[e];            // gcol | gi6 | gpinv are contiguous
+    if (LANE < 48) {
+        const int ft = LANE / 24, ax = (LANE % 24) / 8, k = LANE % 8;
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                if (ax == a && k == kk) v = ft ? P.lF[a][kk] : P.rF[a][kk];
+            }
+        L[P_POLY + LANE] = v;
+    } else if (LANE < 54) {
+        const int q = LANE - 48;
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { if (q == a) n = P.rFn[a]; if (q == 3 + a) n = P.lFn[a]; }
+        L[P_POLY + LANE] = (double)n;
+    }
     load_tables(L);
     WSYNC();
 }
 
-__device__ void store_out(const double *L, double *out)
+__device__ __forceinline__ void store_out(const double *L, double *out)
 {
     const int lane = LANE;
     if (lane < 24) out[lane] = L[P_TAU + lane];

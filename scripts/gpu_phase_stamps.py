@@ -27,3 +27,9 @@ q = d[:, 4010:4014]
 sub = np.stack([q[:, 0] - st_[:, 7], q[:, 1] - q[:, 0], q[:, 2] - q[:, 1], q[:, 3] - q[:, 2], st_[:, 8] - q[:, 3]], axis=1).mean(axis=0)
 for n, c in zip(['qp:woodbury', 'qp:schur+W', 'qp:WG,P', 'qp:cone solve', 'qp:recover'], sub):
     print("  %-14s %8.0f cycles  %5.1f%%" % (n, c, 100 * c / tot.mean()))
+# per-solve stamps inside the cone QP loop (instruction-cache warm-up shows as solve 1 >> solve 2..)
+for itn in range(1, 7):
+    m = s[:, 1] >= itn
+    if m.sum() == 0: break
+    dur_i = d[m, 4021 + 2 * itn] - d[m, 4020 + 2 * itn]
+    print("  cone solve #%d: n=%4d  mean %7.0f cycles  (mean |F| %.1f)" % (itn, m.sum(), dur_i.mean(), d[m, 4050 + itn].mean()))
