@@ -133,19 +133,26 @@ enum {
 
 #define LANE ((int)threadIdx.x)
 
-// (X m)[k] for X = [E' 0; B E'],  m = [ang; lin]   (generalizedFunctions.cpp:11-19)
+// (X m)[k] for X = [E' 0; B E'],  m = [ang; lin]   (generalizedFunctions.cpp:11-19); branch-free
 __device__ __forceinline__ double x_mot(const double *E, const double *Bm, const double *m, int k)
 {
-    if (k < 3) return E[k] * m[0] + E[3 + k] * m[1] + E[6 + k] * m[2];
-    const int a = k - 3;
-    return Bm[a * 3] * m[0] + Bm[a * 3 + 1] * m[1] + Bm[a * 3 + 2] * m[2] + E[a] * m[3] + E[3 + a] * m[4] + E[6 + a] * m[5];
+    const bool up = k < 3;
+    const int a = up ? k : k - 3;
+    const double *p = up ? E + a : Bm + 3 * a;
+    const int st = up ? 3 : 1;
+    const double t1 = p[0] * m[0] + p[st] * m[1] + p[2 * st] * m[2];
+    const double t2 = E[a] * m[3] + E[3 + a] * m[4] + E[6 + a] * m[5];
+    return up ? t1 : t1 + t2;
 }
-// (X' f)[k],  X' = [E B'; 0 E]
+// (X' f)[k],  X' = [E B'; 0 E]; branch-free
 __device__ __forceinline__ double x_force(const double *E, const double *Bm, const double *f, int k)
 {
-    if (k < 3) return E[k * 3] * f[0] + E[k * 3 + 1] * f[1] + E[k * 3 + 2] * f[2] + Bm[k] * f[3] + Bm[3 + k] * f[4] + Bm[6 + k] * f[5];
-    const int a = k - 3;
-    return E[a * 3] * f[3] + E[a * 3 + 1] * f[4] + E[a * 3 + 2] * f[5];
+    const bool up = k < 3;
+    const int a = up ? k : k - 3;
+    const double *g = up ? f : f + 3;
+    const double t1 = E[a * 3] * g[0] + E[a * 3 + 1] * g[1] + E[a * 3 + 2] * g[2];
+    const double t2 = Bm[a] * f[3] + Bm[3 + a] * f[4] + Bm[6 + a] * f[5];
+    return up ? t1 + t2 : t1;
 }
 // dense X[r][c]
 __device__ __forceinline__ double x_dense(const double *E, const double *Bm, int r, int c)
@@ -472,96 +479,115 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
 }
 
 // Dynamics::computeM (CRBA, Dynamics.cpp:62-101) -> Mtop = [Ic0 | F2], Hl (per-limb joint blocks)
+// Lane map for the composite-inertia recursion: 12 lanes per chain = (row r, 3-column block cb), each
+// lane produces three entries; all five chains advance one level per pass.
+__device__ __forceinline__ void crba_y(double *L, int i, int slot, int r, int cb)      // Y = Ic_i X_i  (rows r, cols 3cb..3cb+2)
+{
+    const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
+    const double l0 = cb ? 0.0 : I[0], l1 = cb ? 0.0 : I[1], l2 = cb ? 0.0 : I[2];
+    const double h0 = I[3], h1 = I[4], h2 = I[5];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        // X[k][c] (k<3) = E[c][k];  X[3+k][c] = B[k][c];  X[3+k][3+c] = E[c][k]
+        const double x0 = cb ? E[3 * c] : Bm[c], x1 = cb ? E[3 * c + 1] : Bm[3 + c], x2 = cb ? E[3 * c + 2] : Bm[6 + c];
+        L[A_YT + 36 * slot + 6 * r + 3 * cb + c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + h0 * x0 + h1 * x1 + h2 * x2;
+    }
+}
+__device__ __forceinline__ void crba_z(const double *L, int i, int slot, int r, int cb, double out[3])   // (X_i' Y)(r, 3cb..)
+{
+    const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i, *Y = L + A_YT + 36 * slot + 3 * cb;
+    const bool up = r < 3;
+    const int a = up ? r : r - 3;
+    // X[k][r] (k<3) = E[r][k] (r<3) or 0;  X[3+k][r] = B[k][r] (r<3) or E[a][k]
+    const double lo0 = up ? E[3 * a] : 0.0, lo1 = up ? E[3 * a + 1] : 0.0, lo2 = up ? E[3 * a + 2] : 0.0;
+    const double hi0 = up ? Bm[a] : E[3 * a], hi1 = up ? Bm[3 + a] : E[3 * a + 1], hi2 = up ? Bm[6 + a] : E[3 * a + 2];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        out[c] = lo0 * Y[c] + lo1 * Y[6 + c] + lo2 * Y[12 + c] + hi0 * Y[18 + c] + hi1 * Y[24 + c] + hi2 * Y[30 + c];
+}
+
 __device__ __forceinline__ void phase_crba(double *L)
 {
     const int lane = LANE;
     // composite inertias start as the body inertias: [Ibar, [h]x; -[h]x, m 1]   (Dynamics.cpp:4-13)
-    for (int e = lane; e < 25 * 36; e += 64) {
-        const int i = f_body(e / 36), r = (e % 36) / 6, c = e % 6;
+    for (int e = lane; e < 150; e += 64) {
+        const int i = f_body(e / 6), r = e % 6;
         const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
-        double val;
-        if (r < 3 && c < 3) val = mo[3 * r + c];
-        else if (r >= 3 && c >= 3) val = (r == c) ? mo[12] : 0.0;
-        else {
-            const int a = r % 3, b = c % 3;                        // [h]x(a,b)
-            double cm = 0.0;
-            if (a != b) {
-                const int k = 3 - a - b;
-                cm = (((b - a + 3) % 3) == 2) ? mo[9 + k] : -mo[9 + k];   // (0,2)=+hy? see below
-            }
-            // [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]: (a,b) with b = a+1 (mod 3) -> -h_k, b = a+2 -> +h_k
-            val = (r < 3) ? cm : -cm;
-        }
-        L[A_IC + 36 * i + 6 * r + c] = val;
+        double *o = L + A_IC + 36 * i + 6 * r;
+        const bool up = r < 3;
+        const int a = up ? r : r - 3;
+        const double hx = mo[9], hy = mo[10], hz = mo[11], m = mo[12];
+        // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]
+        const double c0 = (a == 0) ? 0.0 : (a == 1) ? hz : -hy;
+        const double c1 = (a == 0) ? -hz : (a == 1) ? 0.0 : hx;
+        const double c2 = (a == 0) ? hy : (a == 1) ? -hx : 0.0;
+        if (up) { o[0] = mo[3 * a]; o[1] = mo[3 * a + 1]; o[2] = mo[3 * a + 2]; o[3] = c0; o[4] = c1; o[5] = c2; }
+        else { o[0] = -c0; o[1] = -c1; o[2] = -c2; o[3] = (a == 0) ? m : 0.0; o[4] = (a == 1) ? m : 0.0; o[5] = (a == 2) ? m : 0.0; }
     }
-    for (int lv = 0; lv < 5; lv++) {
-        const int dl = 6 - lv;                                      // chain depth of this level (6..2)
+    const int ch = lane / 12, t = lane % 12, r = t >> 1, cb = t & 1;
+    for (int dl = 6; dl >= 2; dl--) {                              // chain depth of the frames folded into their parents
         const int nf = (dl == 6) ? 2 : (dl >= 3) ? 4 : 5;
+        const bool on = lane < 12 * nf;
+        const int i = f_chain_base(ch) + dl - 1;
         WSYNC();
-        for (int e = lane; e < nf * 36; e += 64) {                 // Y = Ic_i X_i
-            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = f_chain_base(sl) + dl - 1;
-            const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
-            double s = 0.0;
-            if (c < 3) { for (int k = 0; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
-            else { for (int k = 3; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
-            L[A_YT + e] = s;
-        }
+        if (on) crba_y(L, i, ch, r, cb);
         WSYNC();
-        for (int e = lane; e < nf * 36; e += 64) {                 // Ic_parent += X_i' Y
-            const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = f_chain_base(sl) + dl - 1;
-            const double *Y = L + A_YT + 36 * sl + c, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
-            double s = 0.0;
-            if (r < 3) { for (int k = 0; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
-            else { for (int k = 3; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
-            L[A_IC + 36 * f_parent(i) + 6 * r + c] += s;
+        if (on) {
+            double z[3];
+            crba_z(L, i, ch, r, cb, z);
+            double *o = L + A_IC + 36 * (i - 1) + 6 * r + 3 * cb;  // parent of a depth >= 2 frame is i-1
+            o[0] += z[0]; o[1] += z[1]; o[2] += z[2];
         }
     }
     WSYNC();
-    for (int e = lane; e < 5 * 36; e += 64) {                      // depth-1 frames: Y
-        const int sl = e / 36, r = (e % 36) / 6, c = e % 6, i = f_root(sl);
-        const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
-        double s = 0.0;
-        if (c < 3) { for (int k = 0; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
-        else { for (int k = 3; k < 6; k++) s += I[k] * x_dense(E, Bm, k, c); }
-        L[A_YT + e] = s;
+    if (lane < 60) crba_y(L, f_root(ch), ch, r, cb);               // depth-1 frames, slots in the reference's order
+    WSYNC();
+    if (lane < 60) {
+        double z[3];
+        crba_z(L, f_root(ch), ch, r, cb, z);
+        double *o = L + A_FB + 36 * ch + 6 * r + 3 * cb;           // park the five contributions
+        o[0] = z[0]; o[1] = z[1]; o[2] = z[2];
     }
     WSYNC();
-    if (lane < 36) {                                               // Ic0 += sum in reference order
-        const int r = lane / 6, c = lane % 6;
+    if (lane < 36) {                                               // Ic0 += head, LA, RA, LL, RL (Dynamics.cpp:80-82 order)
         double acc = L[A_IC + lane];
-        for (int sl = 0; sl < 5; sl++) {
-            const int i = f_root(sl);
-            const double *Y = L + A_YT + 36 * sl + c, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
-            double s = 0.0;
-            if (r < 3) { for (int k = 0; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
-            else { for (int k = 3; k < 6; k++) s += x_dense(E, Bm, k, r) * Y[6 * k]; }
-            acc += s;
-        }
-        L[P_MTOP + 30 * r + c] = acc;
-    }
-    // joint columns: f = Ic_i S, walked up the chain (Dynamics.cpp:83-93)
-    for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
-    for (int e = lane; e < 144; e += 64) {
-        const int a = e / 6, k = e % 6;
-        L[A_FB + e] = L[A_IC + 36 * f_jframe(a) + 6 * k + 2];
+#pragma unroll
+        for (int sl = 0; sl < 5; sl++) acc += L[A_FB + 36 * sl + lane];
+        L[P_MTOP + 30 * (lane / 6) + lane % 6] = acc;
     }
     WSYNC();
-    if (lane < 24) L[P_HL + 6 * lane + (lane - f_jstart(lane))] = L[A_FB + 6 * lane + 2];
+    // joint columns: f = Ic_i S, walked up the chain (Dynamics.cpp:83-93); 2 lanes per joint (k<3 | k>=3)
+    for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
+    const int ja = lane >> 1, hf = lane & 1;
+    const int jf = f_jframe(ja), jst = f_jstart(ja), jd = ja - jst + 1;
+    if (lane < 48) {
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) L[A_FB + 6 * ja + 3 * hf + kk] = L[A_IC + 36 * jf + 6 * (3 * hf + kk) + 2];
+    }
+    WSYNC();
+    if (lane < 48 && hf == 0) L[P_HL + 6 * ja + (ja - jst)] = L[A_FB + 6 * ja + 2];
     int cur = 0;
-    for (int s = 1; s <= 6; s++) {
+    for (int sdep = 1; sdep <= 6; sdep++) {
         WSYNC();
-        for (int e = lane; e < 144; e += 64) {
-            const int a = e / 6, k = e % 6, dpt = f_jdepth(a);
-            if (s <= dpt) {
-                const int j = f_jframe(a) - (s - 1);               // frame whose X' is applied
-                const double val = x_force(L + A_XE + 9 * j, L + A_XB + 9 * j, L + A_FB + 144 * cur + 6 * a, k);
-                L[A_FB + 144 * (cur ^ 1) + e] = val;
-                if (s == dpt) L[P_MTOP + 30 * k + 6 + a] = val;    // F2 column
-                else if (k == 2) {
-                    const int aj = a - s;                          // joint of parent(j)
-                    L[P_HL + 6 * aj + (a - f_jstart(a))] = val;
-                    L[P_HL + 6 * a + (aj - f_jstart(a))] = val;
-                }
+        if (lane < 48 && sdep <= jd) {
+            const int j = jf - (sdep - 1);                         // frame whose X' is applied
+            const double *E = L + A_XE + 9 * j, *Bm = L + A_XB + 9 * j, *f = L + A_FB + 144 * cur + 6 * ja;
+            const double *g = hf ? f + 3 : f;
+            double o3[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                const double t1 = E[3 * kk] * g[0] + E[3 * kk + 1] * g[1] + E[3 * kk + 2] * g[2];
+                const double t2 = Bm[kk] * f[3] + Bm[3 + kk] * f[4] + Bm[6 + kk] * f[5];
+                o3[kk] = hf ? t1 : t1 + t2;
+                L[A_FB + 144 * (cur ^ 1) + 6 * ja + 3 * hf + kk] = o3[kk];
+            }
+            if (sdep == jd) {
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) L[P_MTOP + 30 * (3 * hf + kk) + 6 + ja] = o3[kk];    // F2 column
+            } else if (hf == 0) {
+                const int aj = ja - sdep;                          // joint of parent(j)
+                L[P_HL + 6 * aj + (ja - jst)] = o3[2];
+                L[P_HL + 6 * ja + (aj - jst)] = o3[2];
             }
         }
         cur ^= 1;
