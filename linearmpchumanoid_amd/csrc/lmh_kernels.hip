@@ -128,7 +128,8 @@ enum {
     C_WG = S0 + 0,    // 12 x 32
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
     C_LS = S0 + 1440, // 32 x 33 rows of L for the backward substitution
-    LDS_DOUBLES = S0 + 2548
+    C_IDX = S0 + 2496, // 32 ints: compact position -> coefficient index
+    LDS_DOUBLES = S0 + 2512
 };
 
 #define LANE ((int)threadIdx.x)
@@ -776,25 +777,51 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
 }
 
 
-// Solve P_FF z_F = qv_F on the free set F: rows/columns outside F are masked out of a fixed
-// 32 x 32 register-resident LDL' (their pivots are skipped).  Returns z_j for lane j in F (0 otherwise)
-// and, for lanes j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
+// Compacted solve for |F| <= N: lane r < nF owns free index idx[r]; the N x N register LDL' then only
+// visits live pivots.  z of coefficient j comes back through LDS (P_CC).
+template <int N>
+__device__ __forceinline__ int solve_compact(double *L, int nF, int pos, bool inF)
+{
+    const int lane = LANE;
+    const int *idx = (const int *)(L + C_IDX);
+    double a[N], b[1];
+    {
+        const bool on = lane < nF;
+        const int ia = on ? idx[lane] : 0;
+        const double *Pr = L + C_P + 33 * ia;
+#pragma unroll
+        for (int c = 0; c < N; c++) a[c] = (on && c <= lane) ? Pr[idx[c]] : 0.0;     // idx[c] for c >= nF is a stale but valid index
+        b[0] = on ? L[P_QV + ia] : 0.0;
+    }
+    const int bad = ldl_solve_regs<N, 1>(a, b, (nF >= 32) ? 0xFFFFFFFFu : ((1u << nF) - 1u), L + C_LS);
+    WSYNC();
+    if (lane < 32) L[P_CC + lane] = 0.0;
+    WSYNC();
+    if (lane < nF) L[P_CC + idx[lane]] = b[0];
+    WSYNC();
+    (void)pos; (void)inF;
+    return bad;
+}
+
+// Solve P_FF z_F = qv_F on the free set F.  Returns z_j for lane j in F (0 otherwise) and, for lanes
+// j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
 __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
 {
     const int lane = LANE, r = lane & 31, half = lane >> 5;
     const bool inF = (lane < 32) && ((F >> lane) & 1u);
-    double a[32], b[1];
-    {
-        const double *Pr = L + C_P + 33 * r;
-#pragma unroll
-        for (int c = 0; c < 32; c++) a[c] = (inF && ((F >> c) & 1u)) ? Pr[c] : 0.0;
-        b[0] = inF ? L[P_QV + r] : 0.0;
-    }
-    const int bad = ldl_solve_regs<32, 1>(a, b, F, L + C_LS);
-    const double zj = inF ? b[0] : 0.0;
+    const int nF = __popc(F);
+    const int pos = __popc(F & ((1u << r) - 1u));
+    int *idx = (int *)(L + C_IDX);
     WSYNC();
-    if (lane < 32) L[P_CC + lane] = zj;
+    if (lane < 32) idx[lane] = 0;
     WSYNC();
+    if (inF) idx[pos] = lane;
+    WSYNC();
+    int bad;
+    if (nF <= 8) bad = solve_compact<8>(L, nF, pos, inF);
+    else if (nF <= 16) bad = solve_compact<16>(L, nF, pos, inF);
+    else bad = solve_compact<32>(L, nF, pos, inF);
+    const double zj = (lane < 32) ? L[P_CC + lane] : 0.0;
     double s = 0.0;
     {
         const double *Pr = L + C_P + 33 * r + 16 * half, *cc = L + P_CC + 16 * half;
@@ -802,7 +829,7 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_o
         for (int bq = 0; bq < 16; bq++) s += Pr[bq] * cc[bq];
     }
     s += __shfl_xor(s, 32, 64);
-    *z_out = zj;
+    *z_out = inF ? zj : 0.0;
     *lam_out = (lane < 32 && !((F >> lane) & 1u)) ? s - L[P_QV + r] : 0.0;
     return bad;
 }
@@ -988,7 +1015,14 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         for (int c = 0; c < 18; c++) a[c] = (on && c <= lane) ? L[B_K + ld * lane + c] : 0.0;
 #pragma unroll
         for (int r = 0; r < 7; r++) bb[r] = on ? L[B_K + ld * (nU + r) + lane] : 0.0;
-        if (ldl_solve_regs<18, 7>(a, bb, (1u << nU) - 1u, L + B_LS)) flags |= LMH_FLAG_NOT_SPD;
+        int badw;
+        if (nU == 15) {
+            double a15[15];
+#pragma unroll
+            for (int c = 0; c < 15; c++) a15[c] = a[c];
+            badw = ldl_solve_regs<15, 7>(a15, bb, 0x7FFFu, L + B_LS);
+        } else badw = ldl_solve_regs<18, 7>(a, bb, (1u << nU) - 1u, L + B_LS);
+        if (badw) flags |= LMH_FLAG_NOT_SPD;
         if (on) {
 #pragma unroll
             for (int r = 0; r < 7; r++) L[B_K + ld * (nU + r) + lane] = bb[r];
