@@ -19,8 +19,9 @@
  *       v_prev is Robot::v_ as the previous Controller::standStep left it: the reference
  *       evaluates C, Cg and Jdot*qdot BEFORE it stores the new velocity
  *       (src/controller.cpp:56 vs :59), so those terms see the previous call's velocity.
- *   out    [B][LMH_OUT_STRIDE]    : tau(24) | f(12: n_R f_R n_L f_L) | qdd(30) | pad(6)
- *       (WBCOutput, controller.hpp:43-48)
+ *   out    [B][LMH_OUT_STRIDE]    : tau(24) | f(12: n_R f_R n_L f_L) | qdd(30) | CoM(3) | comVel(3) |
+ *                                   xRef(3) | yRef(3) | pad(2)
+ *       (WBCOutput, controller.hpp:43-48; Robot::getCoM/getComVel; Mpc3dLip::getXRef/getYRef)
  *   status [B][LMH_STATUS_STRIDE] int32 : k | qp_iterations | flags | active_mask
  *       k = int(t/dt) of the last evaluation (src/mpcLinearPendulum.cpp:92), bit-exact.
  */
@@ -36,7 +37,7 @@ extern "C" {
 #define LMH_NJ 24
 #define LMH_NFRAMES 28
 #define LMH_STATE_STRIDE 96
-#define LMH_OUT_STRIDE 72
+#define LMH_OUT_STRIDE 80
 #define LMH_STATUS_STRIDE 4
 #define LMH_LINK_STRIDE 13        /* mass | com(3) | inertia(9 row-major), linkInertia.hpp:4-9 */
 #define LMH_MAX_HORIZON 64
@@ -138,10 +139,20 @@ int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status
 int lmh_ik(lmh_handle *h, double *d_q, const double *com_target, const double *rf6, const double *lf6,
            int32_t *d_iters, void *stream);
 
+/* replaces: Robot::updateState + Robot::getCoM (src/Robot.cpp:264-269,225-238).
+ * DEVICE d_q [B][30] in, d_com [B][3] out. */
+int lmh_robot_com(lmh_handle *h, const double *d_q, double *d_com, void *stream);
+
 /* host-buffer convenience used by the C++ shim (B instances, staged through internal
  * device buffers, synchronous): q/dq [B][30], t, outputs tau[B][24], f[B][12], qdd[B][30] */
 int lmh_eval_host(lmh_handle *h, const double *q, const double *dq, double t,
                   double *tau, double *f, double *qdd, int32_t *status);
+/* Robot::updateState + getCoM through host buffers: q [B][30] in, com [B][3] out */
+int lmh_robot_com_host(lmh_handle *h, const double *q, double *com);
+/* full out records of the last lmh_eval_host call: HOST [B][LMH_OUT_STRIDE] */
+int lmh_last_out_host(lmh_handle *h, double *out);
+/* Kinematics::compute + Robot::getCoM through host buffers: q [B][30] in/out, com [B][3] out, iters [B] out */
+int lmh_ik_host(lmh_handle *h, double *q, const double *com_target, const double *rf6, const double *lf6, double *com, int32_t *iters);
 /* overwrite the staged Robot::v_ (v_prev) used by the next lmh_eval_host call: HOST [B][30] */
 int lmh_set_prev_velocity_host(lmh_handle *h, const double *v);
 int lmh_synchronize(lmh_handle *h, void *stream);

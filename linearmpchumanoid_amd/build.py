@@ -28,5 +28,34 @@ def build(force=False, verbose=False):
     return SO
 
 
+SHIM_DIR = os.path.join(CSRC, "shim")
+SHIM_SO = os.path.join(_HERE, "liblmh_shim.so")
+ROOT = os.path.dirname(_HERE)
+OFFLINE_BIN = os.path.join(ROOT, "apps", "offline_stand")
+
+
+def build_shim(force=False, verbose=False):
+    """C++ class surface of the reference (Robot, Controller, ...) over the C ABI + the offline app."""
+    build(force=False)
+    src = os.path.join(SHIM_DIR, "lmh_shim.cpp")
+    app = os.path.join(ROOT, "apps", "offline_stand.cpp")
+    inc = ["-I" + SHIM_DIR, "-I" + os.path.join(ROOT, "include")]
+    newest = max(os.path.getmtime(os.path.join(dp, f)) for dp, _, fs in os.walk(SHIM_DIR) for f in fs)
+    if force or not os.path.exists(SHIM_SO) or os.path.getmtime(SHIM_SO) < max(newest, os.path.getmtime(SO)):
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", *inc, src, "-o", SHIM_SO,
+               "-L" + _HERE, "-llmh_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if force or not os.path.exists(OFFLINE_BIN) or os.path.getmtime(OFFLINE_BIN) < max(os.path.getmtime(app), os.path.getmtime(SHIM_SO)):
+        cmd = ["g++", "-std=c++17", "-O2", *inc, app, "-o", OFFLINE_BIN, "-L" + _HERE, "-llmh_shim", "-llmh_hip",
+               "-Wl,-rpath," + _HERE]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SHIM_SO, OFFLINE_BIN
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_shim(force=True, verbose=True))

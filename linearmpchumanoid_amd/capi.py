@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liblmh_hip.so")
 
 STATE_STRIDE = 96
-OUT_STRIDE = 72
+OUT_STRIDE = 80
 STATUS_STRIDE = 4
 DEBUG_STRIDE = 4096
 LINK_STRIDE = 13
@@ -28,7 +28,7 @@ EXPORTS = [
     "lmh_num_instances", "lmh_horizon", "lmh_set_model", "lmh_get_mass", "lmh_nominal_links",
     "lmh_set_refs", "lmh_set_refs_stance", "lmh_set_foot_coeffs", "lmh_set_zcom", "lmh_get_mpc_gain",
     "lmh_eval", "lmh_eval_debug", "lmh_rollout", "lmh_ik", "lmh_eval_host", "lmh_set_prev_velocity_host",
-    "lmh_synchronize",
+    "lmh_synchronize", "lmh_robot_com", "lmh_robot_com_host", "lmh_last_out_host", "lmh_ik_host",
 ]
 
 
@@ -80,6 +80,10 @@ def lib():
     L.lmh_eval_host.argtypes = [vp, vp, vp, dp, vp, vp, vp, vp]
     L.lmh_set_prev_velocity_host.argtypes = [vp, vp]
     L.lmh_synchronize.argtypes = [vp, vp]
+    L.lmh_robot_com.argtypes = [vp, vp, vp, vp]
+    L.lmh_last_out_host.argtypes = [vp, vp]
+    L.lmh_robot_com_host.argtypes = [vp, vp, vp]
+    L.lmh_ik_host.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("lmh_last_error", "lmh_config_default", "lmh_nominal_links"):

@@ -16,6 +16,7 @@
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s);
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, hipStream_t s);
+extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s);
 extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const double *target, int32_t *iters, hipStream_t s);
 
 static thread_local std::string g_err;
@@ -416,6 +417,54 @@ extern "C" int lmh_eval_host(lmh_handle *h, const double *q, const double *dq, d
         if (qdd) std::memcpy(qdd + 30 * (size_t)i, o + 36, 30 * sizeof(double));
         if (status) std::memcpy(status + 4 * (size_t)i, h->h_status.data() + 4 * (size_t)i, 4 * sizeof(int32_t));
     }
+    return LMH_OK;
+}
+
+extern "C" int lmh_robot_com(lmh_handle *h, const double *d_q, double *d_com, void *stream)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!d_q || !d_com) return fail(LMH_ERR_BAD_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    lmh_launch_com(&h->P, d_q, d_com, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return LMH_OK;
+}
+
+extern "C" int lmh_robot_com_host(lmh_handle *h, const double *q, double *com)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!q || !com) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(h->d_state, q, sizeof(double) * 30 * (size_t)h->B, hipMemcpyHostToDevice));
+    rc = lmh_robot_com(h, h->d_state, h->d_out, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(com, h->d_out, sizeof(double) * 3 * (size_t)h->B, hipMemcpyDeviceToHost));
+    return LMH_OK;
+}
+
+extern "C" int lmh_last_out_host(lmh_handle *h, double *out)
+{
+    if (!h || !out) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    std::memcpy(out, h->h_out.data(), sizeof(double) * h->h_out.size());
+    return LMH_OK;
+}
+
+extern "C" int lmh_ik_host(lmh_handle *h, double *q, const double *com_target, const double *rf6, const double *lf6, double *com, int32_t *iters)
+{
+    int rc = ready(h); if (rc) return rc;
+    if (!q || !com_target || !rf6 || !lf6) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    double *d_q = h->d_state;                                        // staging: reuse the state buffer
+    double *d_com = h->d_out;
+    HIPCHK(hipMemcpy(d_q, q, sizeof(double) * 30 * (size_t)h->B, hipMemcpyHostToDevice));
+    rc = lmh_ik(h, d_q, com_target, rf6, lf6, h->d_status, nullptr);
+    if (rc) return rc;
+    rc = lmh_robot_com(h, d_q, d_com, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(q, d_q, sizeof(double) * 30 * (size_t)h->B, hipMemcpyDeviceToHost));
+    if (com) HIPCHK(hipMemcpy(com, d_com, sizeof(double) * 3 * (size_t)h->B, hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(hipMemcpy(iters, h->d_status, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_status, 0, sizeof(int32_t) * LMH_STATUS_STRIDE * (size_t)h->B));
     return LMH_OK;
 }
 

@@ -1267,6 +1267,8 @@ __device__ __forceinline__ void store_out(const double *L, double *out)
     if (lane < 24) out[lane] = L[P_TAU + lane];
     else if (lane < 36) out[lane] = L[P_W12 + lane - 24];
     for (int e = lane; e < 30; e += 64) out[36 + e] = L[P_QDD + e];
+    if (lane >= 32 && lane < 38) out[66 + lane - 32] = L[P_COM + lane - 32];        // CoM | comVel (Robot::getCoM / getComVel)
+    if (lane >= 40 && lane < 46) out[72 + lane - 40] = L[P_MPC + 2 + lane - 40];    // Mpc3dLip::getXRef | getYRef
 }
 
 // ============================================================================ kernels
@@ -1598,6 +1600,25 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
 extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const double *target, int32_t *iters, hipStream_t s)
 {
     hipLaunchKernelGGL(lmh_ik_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, target, iters);
+}
+
+// Robot::updateState + getCoM (Robot.cpp:264-269,225-238) for q only.
+__global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P, const double *q, double *com)
+{
+    __shared__ double L[LDS_DOUBLES];
+    const int inst = blockIdx.x;
+    if (inst >= P.n_instances) return;
+    load_common(L, P, inst);
+    if (LANE < 30) L[P_Q + LANE] = q[30 * (size_t)inst + LANE];
+    if (LANE < 60) L[P_V + LANE] = 0.0;
+    WSYNC();
+    phase_fk(L);
+    phase_com_x(L);
+    if (LANE < 3) com[3 * (size_t)inst + LANE] = L[P_COM + LANE];
+}
+extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s)
+{
+    hipLaunchKernelGGL(lmh_com_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, com);
 }
 
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s)
