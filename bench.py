@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--cold", action="store_true", help="cold-start the QP active set every evaluation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch from rocprofv3 --pmc (optional)")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="HBM bytes per launch from rocprofv3 --pmc; default: the committed profiles/ summary when the workload matches it")
     return ap.parse_args()
 
 
@@ -86,6 +87,21 @@ def cpu_baseline(q0, zcom, args):
     return {"value": allc, "unit": "control ticks/s", "cores": threads, "kind": "port",
             "single_core_value": one,
             "sample": f"C oracle (-O2), {n_inst} instances x {tk} ticks on {threads} threads; 1 instance x {ticks} ticks on 1 thread; same states/tick function as the GPU run, 1 WBC solve per evaluation"}
+
+
+def profiled_traffic(args):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, profiles/r01_rollout_summary.json); only valid for the workload it was collected on."""
+    if args.traffic is not None:
+        return args.traffic
+    if (args.instances, args.ticks, args.horizon) != (1024, 10, 16) or args.cold:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_rollout_summary.json")) as f:
+            d = json.load(f)["derived"]
+        return d["hbm_write_bytes_per_launch"] + d["hbm_fetch_bytes_per_launch_x2_gfx950_correction"]
+    except Exception:
+        return None
 
 
 def main():
@@ -162,7 +178,7 @@ def main():
                        "qp_start": "cold" if args.cold else "warm", "parallelism": f"instances sharded x{world}"},
             "evaluations_per_s": value * 4,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic, "kernel": "lmh_rollout_kernel", "kernel_ms": kernel_ms,
+                         "traffic": profiled_traffic(args), "kernel": "lmh_rollout_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "fp64_valu": {"achieved_tflops": count * args.ticks * ALG_FLOP_PER_TICK / launch_s / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "frac": count * args.ticks * ALG_FLOP_PER_TICK / launch_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
