@@ -971,6 +971,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         L[B_OB + 18 + lane] = 1.0 / om;
     }
     WSYNC();
+    if (dbgp && LANE == 0) dbgp[4070] = (double)clock64();
     // ---- bp = D^-1 [g_a | Mb'] ; g_a = U' Om beta - D qref   (controller.cpp:127-132)
     for (int e = lane; e < 210; e += 64) {
         const int i = e / 7, cidx = e % 7;
@@ -983,6 +984,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         } else val = L[P_MTOP + 30 * (cidx - 1) + i] * iDi;
         L[B_BP + e] = val;
     }
+    if (dbgp && LANE == 0) dbgp[4071] = (double)clock64();
     // ---- Cm = Om^-1 + U D^-1 U' (lower)
     const int ld = 19;
     for (int e = lane; e < 18 * 18; e += 64) {
@@ -999,6 +1001,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         }
     }
     WSYNC();
+    if (dbgp && LANE == 0) dbgp[4072] = (double)clock64();
     for (int e = lane; e < 7 * 18; e += 64) {                      // V' rows: (U bp)'
         const int cidx = e / 18, r = e % 18;
         if (r < nU) {
@@ -1008,6 +1011,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         }
     }
     WSYNC();
+    if (dbgp && LANE == 0) dbgp[4073] = (double)clock64();
     {   // Cm t = V for the 7 right-hand sides: row-per-lane register LDL'
         double a[18], bb[7];
         const bool on = lane < nU;
@@ -1029,6 +1033,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         }
     }
     WSYNC();
+    if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
     for (int e = lane; e < 210; e += 64) {                         // Y = bp - D^-1 U' t
         const int i = e / 7, cidx = e % 7;
         const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
