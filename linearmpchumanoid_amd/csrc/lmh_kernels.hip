@@ -122,8 +122,9 @@ enum {
     B_BP = S0 + 1016, // 30 x 7
     B_S = S0 + 1226,  // 12 x 7
     B_T1 = S0 + 1310, // 12 x 6
-    B_OB = S0 + 1382, // Om*beta (18) | 1/Om (18)
-    B_LS = S0 + 1420, // 18 x 19 rows of L
+    B_OB = S0 + 1382, // Om*beta (18) | 1/Om (18) | beta (18)
+    B_LS = S0 + 1436, // 18 x 19 rows of L
+    B_CF = S0 + 1778, // 18 x 18 full symmetric copy of Cm
     // ---- phase C (cone QP)
     C_WG = S0 + 0,    // 12 x 32
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
@@ -231,6 +232,23 @@ __device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], un
         for (int r = 0; r < M; r++) b[r] = fma(-lji, bcast_lane(b[r], j), b[r]);
     }
     return bad;
+}
+
+
+// ------------------------------------------------------------------ fp64 matrix-core tiles
+// The small dense contractions of the QP set-up (K = 12..32) run on v_mfma_f64_16x16x4_f64: one
+// 16 x 16 output tile per call, D = sum_k A[:,k] B[k,:].  Fragment maps (gfx950): lane l supplies
+// A[l & 15][4 kk + (l >> 4)] and B[4 kk + (l >> 4)][l & 15]; it receives D[(l >> 4) + 4 reg][l & 15].
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <int KSTEPS, class FA, class FB>
+__device__ __forceinline__ v4d mfma_tile(FA a_of, FB b_of)
+{
+    const int r = LANE & 15, kq = LANE >> 4;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_of(r, 4 * kk + kq), b_of(4 * kk + kq, r), acc, 0, 0, 0);
+    return acc;
 }
 
 // ============================================================================ kinematics
@@ -959,56 +977,69 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     const int r0 = (P.w_com_ang == 0.0) ? 3 : 0;
     const int nU = 18 - r0;
     const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
+    const int tr = lane & 15, tq = lane >> 4;                      // MFMA result: rows tq + 4 reg, column tr
     for (int e = lane; e < nU * 30; e += 64) {
         const int r = r0 + e / 30, c = e % 30;
         L[B_U + e] = (r < 6) ? L[P_AG + 30 * r + c] : jdense(L, r - 6, c);
     }
-    if (lane < nU) {                                               // Om_r * beta_r  and  1 / Om_r
+    if (lane < nU) {                                               // Om_r * beta_r , 1 / Om_r , beta_r
         const int rr = r0 + lane;
         const double om = (rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot;
         const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
         L[B_OB + lane] = om * beta;
         L[B_OB + 18 + lane] = 1.0 / om;
+        L[B_OB + 36 + lane] = beta;
     }
-    WSYNC();
-    if (dbgp && LANE == 0) dbgp[4070] = (double)clock64();
-    // ---- bp = D^-1 [g_a | Mb'] ; g_a = U' Om beta - D qref   (controller.cpp:127-132)
+    // bp' = [-qref | D^-1 Mb']  (the U' Om beta part of g_a is folded into the right-hand side below:
+    // U bp_g = Cm ob - beta - U qref  and  Y_g = D^-1 U'(ob - t_g) - qref; controller.cpp:127-132)
     for (int e = lane; e < 210; e += 64) {
         const int i = e / 7, cidx = e % 7;
         const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
-        double val;
-        if (cidx == 0) {
-            double s = 0.0;
-            for (int r = 0; r < nU; r++) s += L[B_U + 30 * r + i] * L[B_OB + r];
-            val = s * iDi - L[P_QREF + i];
-        } else val = L[P_MTOP + 30 * (cidx - 1) + i] * iDi;
-        L[B_BP + e] = val;
+        L[B_BP + e] = (cidx == 0) ? -L[P_QREF + i] : L[P_MTOP + 30 * (cidx - 1) + i] * iDi;
     }
-    if (dbgp && LANE == 0) dbgp[4071] = (double)clock64();
-    // ---- Cm = Om^-1 + U D^-1 U' (lower)
+    WSYNC();
+    if (dbgp && LANE == 0) dbgp[4070] = (double)clock64();
+    // ---- Cm = Om^-1 + U D^-1 U'  and  V = U bp'  on the matrix cores (K = 30 padded to 32)
     const int ld = 19;
-    for (int e = lane; e < 18 * 18; e += 64) {
-        const int r = e / 18, c = e % 18;
-        if (c <= r && r < nU) {
-            const double *Ur = L + B_U + 30 * r, *Uc = L + B_U + 30 * c;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-            for (int i = 0; i < 3; i++) s0 += Ur[i] * Uc[i];
-            for (int i = 3; i < 6; i++) s1 += Ur[i] * Uc[i];
-            for (int i = 6; i < 30; i++) s2 += Ur[i] * Uc[i];
-            double sum = s0 * idp + s1 * ida + s2 * idj;
-            if (r == c) sum += L[B_OB + 18 + r];
-            L[B_K + ld * r + c] = sum;
+    {
+        auto a_u = [&](int m, int k) { return (m < nU && k < 30) ? L[B_U + 30 * m + k] : 0.0; };
+        auto b_ud = [&](int k, int n) { return (n < nU && k < 30) ? L[B_U + 30 * n + k] * ((k < 3) ? idp : (k < 6) ? ida : idj) : 0.0; };
+        auto b_bp = [&](int k, int n) { return (n < 7 && k < 30) ? L[B_BP + 7 * k + n] : 0.0; };
+        const v4d cm = mfma_tile<8>(a_u, b_ud);
+        const v4d vv = mfma_tile<8>(a_u, b_bp);
+        if (nU > 16) {                                             // rows/cols 16, 17 (angular-momentum weight set): plain loops
+            for (int e = lane; e < 2 * 18; e += 64) {
+                const int r = 16 + e / 18, c = e % 18;
+                if (c <= r) {
+                    double sacc = (r == c) ? L[B_OB + 18 + r] : 0.0;
+                    for (int i = 0; i < 30; i++) sacc += L[B_U + 30 * r + i] * L[B_U + 30 * c + i] * ((i < 3) ? idp : (i < 6) ? ida : idj);
+                    L[B_K + ld * r + c] = sacc;
+                }
+            }
+            for (int e = lane; e < 2 * 7; e += 64) {
+                const int r = 16 + e / 7, cidx = e % 7;
+                double sacc = 0.0;
+                for (int i = 0; i < 30; i++) sacc += L[B_U + 30 * r + i] * L[B_BP + 7 * i + cidx];
+                L[B_K + ld * (nU + cidx) + r] = sacc;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int row = tq + 4 * g;
+            if (row < nU && tr <= row) L[B_K + ld * row + tr] = cm[g] + ((row == tr) ? L[B_OB + 18 + row] : 0.0);
+            if (row < nU && tr < 7) L[B_K + ld * (nU + tr) + row] = vv[g];
+            if (row < nU && tr < nU) L[B_CF + 18 * row + tr] = cm[g] + ((row == tr) ? L[B_OB + 18 + row] : 0.0);   // full copy for Cm ob
         }
     }
     WSYNC();
-    if (dbgp && LANE == 0) dbgp[4072] = (double)clock64();
-    for (int e = lane; e < 7 * 18; e += 64) {                      // V' rows: (U bp)'
-        const int cidx = e / 18, r = e % 18;
-        if (r < nU) {
-            double s = 0.0;
-            for (int i = 0; i < 30; i++) s += L[B_U + 30 * r + i] * L[B_BP + 7 * i + cidx];
-            L[B_K + ld * (nU + cidx) + r] = s;
+    if (lane < nU) {                                               // V_g += Cm ob - beta
+        double sacc = -L[B_OB + 36 + lane];
+        for (int c = 0; c < nU; c++) {
+            const int hi = (c > lane) ? c : lane, lo = (c > lane) ? lane : c;
+            const double cmv = (hi < 16) ? L[B_CF + 18 * lane + c] : L[B_K + ld * hi + lo];
+            sacc += cmv * L[B_OB + c];
         }
+        L[B_K + ld * nU + lane] += sacc;
     }
     WSYNC();
     if (dbgp && LANE == 0) dbgp[4073] = (double)clock64();
@@ -1028,28 +1059,40 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         } else badw = ldl_solve_regs<18, 7>(a, bb, (1u << nU) - 1u, L + B_LS);
         if (badw) flags |= LMH_FLAG_NOT_SPD;
         if (on) {
+            bb[0] -= L[B_OB + lane];                               // t' = t_g - ob in column 0
 #pragma unroll
             for (int r = 0; r < 7; r++) L[B_K + ld * (nU + r) + lane] = bb[r];
         }
     }
     WSYNC();
     if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
-    for (int e = lane; e < 210; e += 64) {                         // Y = bp - D^-1 U' t
-        const int i = e / 7, cidx = e % 7;
-        const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
-        double s = 0.0;
-        for (int r = 0; r < nU; r++) s += L[B_U + 30 * r + i] * L[B_K + ld * (nU + cidx) + r];
-        L[P_Y + e] = L[B_BP + e] - s * iDi;
+    // ---- Y = bp' - D^-1 U' t'   (30 x 7; two row tiles, K = nU padded to 20)
+    {
+        auto b_t = [&](int k, int n) { return (k < nU && n < 7) ? L[B_K + ld * (nU + n) + k] : 0.0; };
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            auto a_ut = [&](int m, int k) { const int i = 16 * mt + m; return (i < 30 && k < nU) ? L[B_U + 30 * k + i] : 0.0; };
+            const v4d yy = mfma_tile<5>(a_ut, b_t);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int i = 16 * mt + tq + 4 * g;
+                if (i < 30 && tr < 7) L[P_Y + 7 * i + tr] = L[B_BP + 7 * i + tr] - yy[g] * ((i < 3) ? idp : (i < 6) ? ida : idj);
+            }
+        }
     }
     WSYNC();
     if (dbgp && LANE == 0) dbgp[4010] = (double)clock64();
-    // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g ; Si = S^-1 via Cholesky with identity rows
-    if (lane < 42) {
-        const int r = lane / 7, cidx = lane % 7;
-        double s = 0.0;
-        for (int i = 0; i < 30; i++) s += L[P_MTOP + 30 * r + i] * L[P_Y + 7 * i + cidx];
-        if (cidx == 0) L[P_D6 + r] = L[P_C + r] - s;
-        else L[B_S + 7 * r + (cidx - 1)] = s;
+    // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g  (one tile, K = 30 padded to 32); Si = S^-1
+    {
+        auto a_m = [&](int m, int k) { return (m < 6 && k < 30) ? L[P_MTOP + 30 * m + k] : 0.0; };
+        auto b_y = [&](int k, int n) { return (n < 7 && k < 30) ? L[P_Y + 7 * k + n] : 0.0; };
+        const v4d sy = mfma_tile<8>(a_m, b_y);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int row = tq + 4 * g;
+            if (row < 6 && tr == 0) L[P_D6 + row] = L[P_C + row] - sy[g];
+            if (row < 6 && tr >= 1 && tr < 7) L[B_S + 7 * row + (tr - 1)] = sy[g];
+        }
     }
     WSYNC();
     {   // Si = S^-1: six unit right-hand sides
@@ -1063,48 +1106,60 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         }
     }
     WSYNC();
-    // ---- T1 = Jb Si (12x6), W = I + T1 Jb', h = T1 d
-    for (int e = lane; e < 72; e += 64) {
-        const int row = e / 6, c = e % 6;
-        double s = 0.0;
-        for (int k = 0; k < 6; k++) s += jdense(L, row, k) * L[P_SI + 6 * k + c];
-        L[B_T1 + e] = s;
+    // ---- T1 = Jb Si (12x6);  [W | h] = [w_force I + T1 Jb' | T1 d]   (K = 6 padded to 8)
+    {
+        auto a_jb = [&](int m, int k) { return (m < 12 && k < 6) ? jdense(L, m, k) : 0.0; };
+        auto b_si = [&](int k, int n) { return (k < 6 && n < 6) ? L[P_SI + 6 * k + n] : 0.0; };
+        const v4d t1 = mfma_tile<2>(a_jb, b_si);
+#pragma unroll
+        for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12 && tr < 6) L[B_T1 + 6 * row + tr] = t1[g]; }
     }
     WSYNC();
-    for (int e = lane; e < 156; e += 64) {
-        if (e < 144) {
-            const int r = e / 12, c = e % 12;
-            double s = (r == c) ? P.w_force : 0.0;
-            for (int k = 0; k < 6; k++) s += L[B_T1 + 6 * r + k] * jdense(L, c, k);
-            L[P_W + e] = s;
-        } else {
-            const int r = e - 144;
-            double s = 0.0;
-            for (int k = 0; k < 6; k++) s += L[B_T1 + 6 * r + k] * L[P_D6 + k];
-            L[P_H12 + r] = s;
+    {
+        auto a_t1 = [&](int m, int k) { return (m < 12 && k < 6) ? L[B_T1 + 6 * m + k] : 0.0; };
+        auto b_jd = [&](int k, int n) { return (k >= 6) ? 0.0 : (n < 12) ? jdense(L, n, k) : (n == 12) ? L[P_D6 + k] : 0.0; };
+        const v4d ww = mfma_tile<2>(a_t1, b_jd);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int row = tq + 4 * g;
+            if (row < 12 && tr < 12) L[P_W + 12 * row + tr] = ww[g] + ((row == tr) ? P.w_force : 0.0);
+            if (row < 12 && tr == 12) L[P_H12 + row] = ww[g];
         }
     }
     WSYNC();
     if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
-    // ---- cone QP data: WG = W G, Pm = G' WG + eps I, qv = G' h   (G columns: [n; f] of foot j/16)
-    for (int e = lane; e < 384; e += 64) {
-        const int r = e / 32, j = e % 32, o = 6 * (j / 16);
-        double s = 0.0;
-        for (int k = 0; k < 6; k++) s += L[P_W + 12 * r + o + k] * L[P_GCOL + 6 * (j & 15) + k];
-        L[C_WG + e] = s;
+    // ---- cone QP data: WG = W G (12 x 32), Pm = G' WG + eps I (32 x 32), qv = G' h ; G[k][j] is the
+    //      generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
+    {
+        auto a_w = [&](int m, int k) { return (m < 12 && k < 12) ? L[P_W + 12 * m + k] : 0.0; };
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            auto b_g = [&](int k, int n) { const int kk = k - 6 * nt; return (kk >= 0 && kk < 6) ? L[P_GCOL + 6 * n + kk] : 0.0; };
+            const v4d wg = mfma_tile<3>(a_w, b_g);
+#pragma unroll
+            for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12) L[C_WG + 32 * row + 16 * nt + tr] = wg[g]; }
+        }
     }
     if (lane < 32) {
         const int o = 6 * (lane / 16);
-        double s = 0.0;
-        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
-        L[P_QV + lane] = s;
+        double sacc = 0.0;
+        for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
+        L[P_QV + lane] = sacc;
     }
     WSYNC();
-    for (int e = lane; e < 1024; e += 64) {
-        const int i = e / 32, j = e % 32, o = 6 * (i / 16);
-        double s = (i == j) ? P.eps_coeff : 0.0;
-        for (int k = 0; k < 6; k++) s += L[P_GCOL + 6 * (i & 15) + k] * L[C_WG + 32 * (o + k) + j];
-        L[C_P + 33 * i + j] = s;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        auto a_gt = [&](int m, int k) { const int kk = k - 6 * mt; return (kk >= 0 && kk < 6) ? L[P_GCOL + 6 * m + kk] : 0.0; };
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            auto b_wg = [&](int k, int n) { return (k < 12) ? L[C_WG + 32 * k + 16 * nt + n] : 0.0; };
+            const v4d pp = mfma_tile<3>(a_gt, b_wg);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int i = 16 * mt + tq + 4 * g, j = 16 * nt + tr;
+                L[C_P + 33 * i + j] = pp[g] + ((i == j) ? P.eps_coeff : 0.0);
+            }
+        }
     }
     WSYNC();
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();

@@ -35,7 +35,7 @@ for itn in range(1, 7):
     print("  cone solve #%d: n=%4d  mean %7.0f cycles  (mean |F| %.1f)" % (itn, m.sum(), dur_i.mean(), d[m, 4050 + itn].mean()))
 
 w = d[:, 4070:4075]
-names_w = ['wb:U fill+OB', 'wb:bp', 'wb:Cm', 'wb:V', 'wb:LDL 15x7', 'wb:Y']
-t_w = np.stack([w[:,0]-st_[:,7], w[:,1]-w[:,0], w[:,2]-w[:,1], w[:,3]-w[:,2], w[:,4]-w[:,3], q[:,0]-w[:,4]], axis=1).mean(axis=0)
+names_w = ['wb:U,bp fill', 'wb:Cm,V mfma', 'wb:LDL', 'wb:Y mfma']
+t_w = np.stack([w[:,0]-st_[:,7], w[:,3]-w[:,0], w[:,4]-w[:,3], q[:,0]-w[:,4]], axis=1).mean(axis=0)
 for n, c in zip(names_w, t_w):
     print("  %-14s %8.0f cycles" % (n, c))
