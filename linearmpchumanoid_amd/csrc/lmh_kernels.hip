@@ -202,6 +202,7 @@ __device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], un
 {
     const int lane = LANE;
     int bad = 0;
+    double myinv = 0.0;                                           // 1 / d_lane (0 on rows that are not live)
 #pragma unroll
     for (int j = 0; j < N; j++) {
         if (!((live >> j) & 1u)) continue;                        // wave-uniform
@@ -209,15 +210,16 @@ __device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], un
         if (!(d > 0.0)) bad = 1;
         const double invd = fast_rcp(d);
         const double f = a[j] * invd;                             // L_ij in lanes i > j
+        const double fm = (lane > j) ? f : 0.0;
+        if (lane == j) myinv = invd;
 #pragma unroll
         for (int c = j + 1; c < N; c++) a[c] = fma(-f, bcast_lane(a[j], c), a[c]);   // lane c still holds d_j L_cj
 #pragma unroll
-        for (int r = 0; r < M; r++) {
-            const double zj = bcast_lane(b[r], j);
-            b[r] = (lane > j) ? fma(-f, zj, b[r]) : ((lane == j) ? zj * invd : b[r]);
-        }
+        for (int r = 0; r < M; r++) b[r] = fma(-fm, bcast_lane(b[r], j), b[r]);      // forward substitution
         if (lane > j) a[j] = f;
     }
+#pragma unroll
+    for (int r = 0; r < M; r++) b[r] *= myinv;                    // w = D^-1 z
     WSYNC();
     if (lane < N) {
 #pragma unroll
