@@ -42,6 +42,7 @@ extern "C" {
 #define LMH_LINK_STRIDE 13        /* mass | com(3) | inertia(9 row-major), linkInertia.hpp:4-9 */
 #define LMH_MAX_HORIZON 64
 #define LMH_DEBUG_STRIDE 4096
+#define LMH_SEG_STRIDE 52
 
 /* status flags */
 #define LMH_FLAG_QP_MAXITER 1     /* active-set iteration cap hit (reference: "QP failed", controller.cpp:472-476) */
@@ -114,6 +115,15 @@ int lmh_set_refs_stance(lmh_handle *h, double simulation_time, int support_foot)
 /* replaces: footCoeffTrajectory output copied into Controller (src/footRefTrajectory.cpp:4-47,
  * src/controller.cpp:15-16).  coeff: HOST [3][8] ascending powers, n: [3] counts. */
 int lmh_set_foot_coeffs(lmh_handle *h, const double *r_coeff, const int32_t *r_n, const double *l_coeff, const int32_t *l_n);
+/* Build-defined walking extension (the reference declares ZMP::walkZMP, zmpGeneration.hpp:22, but never
+ * defines it; footCoeffTrajectory produces one polynomial set per step).  Piecewise foot references:
+ * segment record = LMH_SEG_STRIDE doubles: t0 | rF[3][8] | lF[3][8] | pad(3), ascending powers, evaluated
+ * at (t - t0); seg_of_sample[k] selects the segment from the preview index k.  HOST pointers;
+ * n_seg = 0 restores the single polynomial set of lmh_set_foot_coeffs. */
+int lmh_set_segments(lmh_handle *h, const double *segs, int n_seg, const uint16_t *seg_of_sample, int n_samples);
+/* per-instance scale of the ZMP x samples and of the x-axis foot polynomials (step length): HOST [n_instances]
+ * or NULL for 1.0 */
+int lmh_set_xscale(lmh_handle *h, const double *xscale, int n);
 /* per-instance LIPM height (domain randomisation): HOST [n_instances]; rebuilds the gain rows */
 int lmh_set_zcom(lmh_handle *h, const double *z_com, int n);
 /* MPC gain row K (HOST out [N+1]) with u0 = -K (Px x_k - zmp[k:k+N+1]); instance 0 */

@@ -14,6 +14,7 @@ OUT_STRIDE = 80
 STATUS_STRIDE = 4
 DEBUG_STRIDE = 4096
 LINK_STRIDE = 13
+SEG_STRIDE = 52
 
 FLAG_QP_MAXITER = 1
 FLAG_NONFINITE = 2
@@ -28,7 +29,7 @@ EXPORTS = [
     "lmh_num_instances", "lmh_horizon", "lmh_set_model", "lmh_get_mass", "lmh_nominal_links",
     "lmh_set_refs", "lmh_set_refs_stance", "lmh_set_foot_coeffs", "lmh_set_zcom", "lmh_get_mpc_gain",
     "lmh_eval", "lmh_eval_debug", "lmh_rollout", "lmh_ik", "lmh_eval_host", "lmh_set_prev_velocity_host",
-    "lmh_synchronize", "lmh_robot_com", "lmh_robot_com_host", "lmh_last_out_host", "lmh_ik_host",
+    "lmh_synchronize", "lmh_robot_com", "lmh_robot_com_host", "lmh_last_out_host", "lmh_ik_host", "lmh_set_segments", "lmh_set_xscale",
 ]
 
 
@@ -84,6 +85,8 @@ def lib():
     L.lmh_last_out_host.argtypes = [vp, vp]
     L.lmh_robot_com_host.argtypes = [vp, vp, vp]
     L.lmh_ik_host.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.lmh_set_segments.argtypes = [vp, vp, ip, vp, ip]
+    L.lmh_set_xscale.argtypes = [vp, vp, ip]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("lmh_last_error", "lmh_config_default", "lmh_nominal_links"):

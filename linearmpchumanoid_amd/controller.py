@@ -102,6 +102,23 @@ class BatchedController:
         rn = np.ascontiguousarray(r_n, dtype=np.int32); ln = np.ascontiguousarray(l_n, dtype=np.int32)
         check(capi.lib().lmh_set_foot_coeffs(self._h, _np_ptr(r), _np_ptr(rn), _np_ptr(l), _np_ptr(ln)))
 
+    def set_segments(self, segs, seg_of_sample):
+        """Walking extension: piecewise foot polynomials [n_seg,52] selected by seg_of_sample[k] (uint16)."""
+        if segs is None:
+            check(capi.lib().lmh_set_segments(self._h, None, 0, None, 0))
+            return
+        sg = np.ascontiguousarray(segs, dtype=np.float64)
+        so = np.ascontiguousarray(seg_of_sample, dtype=np.uint16)
+        check(capi.lib().lmh_set_segments(self._h, _np_ptr(sg), sg.shape[0], _np_ptr(so), len(so)))
+
+    def set_xscale(self, xscale):
+        """Per-instance step-length scale of ZMP x and x-axis foot polynomials ([B] or None)."""
+        if xscale is None:
+            check(capi.lib().lmh_set_xscale(self._h, None, 0))
+            return
+        xs = np.ascontiguousarray(xscale, dtype=np.float64)
+        check(capi.lib().lmh_set_xscale(self._h, _np_ptr(xs), len(xs)))
+
     def set_zcom(self, z_com):
         z = np.atleast_1d(np.ascontiguousarray(z_com, dtype=np.float64))
         check(capi.lib().lmh_set_zcom(self._h, _np_ptr(z), len(z)))

@@ -27,6 +27,9 @@ struct lmh_handle {
     lmh_config cfg;
     int B = 0, device = 0, N = 0, n_models = 0, n_gain = 0, n_samples = 0;
     double *d_model = nullptr, *d_mpc = nullptr, *d_zx = nullptr, *d_zy = nullptr, *d_gcol = nullptr, *d_raw = nullptr;
+    double *d_segs = nullptr, *d_xscale = nullptr;
+    uint16_t *d_sos = nullptr;
+    int n_seg = 0;
     uint8_t *d_phase = nullptr;
     // staging for the host-buffer convenience calls
     double *d_state = nullptr, *d_out = nullptr, *d_tgt = nullptr;
@@ -176,6 +179,7 @@ static void fill_params(lmh_handle *h)
     LmhDevParams &P = h->P;
     const lmh_config &c = h->cfg;
     P.model = h->d_model; P.mpc = h->d_mpc; P.zmpx = h->d_zx; P.zmpy = h->d_zy; P.phase = h->d_phase; P.gcol = h->d_gcol;
+    P.segs = h->d_segs; P.seg_of_sample = h->d_sos; P.xscale = h->d_xscale; P.n_seg = h->n_seg;
     P.model_stride = (h->n_models > 1) ? LMH_MODEL_STRIDE : 0;
     P.mpc_stride = 3 * (h->N + 1) + 4;
     P.mpc_stride_inst = (h->n_gain > 1) ? P.mpc_stride : 0;
@@ -247,7 +251,8 @@ extern "C" int lmh_destroy(lmh_handle *h)
 {
     if (!h) return LMH_OK;
     (void)hipSetDevice(h->device);
-    void *bufs[] = {h->d_model, h->d_mpc, h->d_zx, h->d_zy, h->d_gcol, h->d_raw, h->d_phase, h->d_state, h->d_out, h->d_status, h->d_tgt};
+    void *bufs[] = {h->d_model, h->d_mpc, h->d_zx, h->d_zy, h->d_gcol, h->d_raw, h->d_phase, h->d_state, h->d_out, h->d_status, h->d_tgt,
+                    h->d_segs, h->d_xscale, h->d_sos};
     for (void *b : bufs) if (b) (void)hipFree(b);
     delete h;
     return LMH_OK;
@@ -301,6 +306,9 @@ extern "C" int lmh_set_refs(lmh_handle *h, const double *zx, const double *zy, c
         HIPCHK(hipMemcpy(h->d_phase, phase, (size_t)n, hipMemcpyHostToDevice));
     }
     h->n_samples = n;
+    if (h->d_sos) { (void)hipFree(h->d_sos); h->d_sos = nullptr; }
+    if (h->d_segs) { (void)hipFree(h->d_segs); h->d_segs = nullptr; }
+    h->n_seg = 0;                                                    // segments are tied to the sample grid
     fill_params(h);
     return LMH_OK;
 }
@@ -322,6 +330,41 @@ extern "C" int lmh_set_foot_coeffs(lmh_handle *h, const double *r, const int32_t
         h->P.rFn[a] = rn[a]; h->P.lFn[a] = ln[a];
         for (int k = 0; k < 8; k++) { h->P.rF[a][k] = r[8 * a + k]; h->P.lF[a][k] = l[8 * a + k]; }
     }
+    return LMH_OK;
+}
+
+extern "C" int lmh_set_segments(lmh_handle *h, const double *segs, int n_seg, const uint16_t *sos, int n_samples)
+{
+    if (!h || n_seg < 0) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->d_segs) { HIPCHK(hipFree(h->d_segs)); h->d_segs = nullptr; }
+    if (h->d_sos) { HIPCHK(hipFree(h->d_sos)); h->d_sos = nullptr; }
+    h->n_seg = 0;
+    if (n_seg > 0) {
+        if (!segs || !sos) return fail(LMH_ERR_BAD_ARG, "null segment table");
+        if (n_samples != h->n_samples) return fail(LMH_ERR_BAD_ARG, "seg_of_sample must cover the ZMP reference samples (call lmh_set_refs first)");
+        for (int i = 0; i < n_samples; i++) if (sos[i] >= n_seg) return fail(LMH_ERR_BAD_ARG, "seg_of_sample entry out of range");
+        HIPCHK(hipMalloc(&h->d_segs, sizeof(double) * LMH_SEG_STRIDE * (size_t)n_seg));
+        HIPCHK(hipMalloc(&h->d_sos, sizeof(uint16_t) * (size_t)n_samples));
+        HIPCHK(hipMemcpy(h->d_segs, segs, sizeof(double) * LMH_SEG_STRIDE * (size_t)n_seg, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sos, sos, sizeof(uint16_t) * (size_t)n_samples, hipMemcpyHostToDevice));
+        h->n_seg = n_seg;
+    }
+    fill_params(h);
+    return LMH_OK;
+}
+
+extern "C" int lmh_set_xscale(lmh_handle *h, const double *xscale, int n)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->d_xscale) { HIPCHK(hipFree(h->d_xscale)); h->d_xscale = nullptr; }
+    if (xscale) {
+        if (n != h->B) return fail(LMH_ERR_BAD_ARG, "n must be n_instances");
+        HIPCHK(hipMalloc(&h->d_xscale, sizeof(double) * (size_t)n));
+        HIPCHK(hipMemcpy(h->d_xscale, xscale, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    fill_params(h);
     return LMH_OK;
 }
 

@@ -4,6 +4,7 @@
 
 #define LMH_MODEL_STRIDE 400  // per model: 28 x 14 doubles (Ibar 9 | m*c 3 | m | pad) + [392] total mass
 #define LMH_BODY_STRIDE 14
+#define LMH_SEG_STRIDE 52
 
 struct LmhDevParams {
     // ---- device buffers
@@ -12,11 +13,15 @@ struct LmhDevParams {
     const double *zmpx;         // [n_samples]
     const double *zmpy;
     const uint8_t *phase;       // [n_samples] or nullptr
-    const double *gcol;         // [32][6]  friction-cone generators in wrench order (n; f)
+    const double *gcol;         // [16][6] friction-cone generators of one foot | (G G')^-1 | G'(G G')^-1
+    const double *segs;         // [n_seg][LMH_SEG_STRIDE] walking segments: t0 | rF[3][8] | lF[3][8] | pad, or nullptr
+    const uint16_t *seg_of_sample; // [n_samples] segment of preview index k
+    const double *xscale;       // [n_instances] per-instance scale of ZMP x and x-axis foot polynomials, or nullptr
     int32_t model_stride;       // 0 = shared model
     int32_t mpc_stride_inst;    // 0 = shared gain row
     int32_t mpc_stride;         // 3*(N+1)+4
     int32_t n_samples;
+    int32_t n_seg;
     int32_t horizon;            // N
     int32_t n_instances;
     int32_t warm_start;

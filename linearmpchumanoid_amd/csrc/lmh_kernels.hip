@@ -730,12 +730,13 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
     const double zcom = mp[3 * (N + 1)];
     {
         const double cxp = L[P_COM], cyp = L[P_COM + 1], vxp = L[P_COMV], vyp = L[P_COMV + 1];
+        const double xs = P.xscale ? P.xscale[inst] : 1.0;       // walking extension: per-instance step length
         double sx = 0.0, sy = 0.0;
         for (int i = lane; i <= N; i += 64) {
             int kk = k + i;
             kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
             const double K = mp[i], px0 = mp[(N + 1) + i], px1 = mp[2 * (N + 1) + i];
-            sx += K * ((px0 * cxp + px1 * vxp) - P.zmpx[kk]);
+            sx += K * ((px0 * cxp + px1 * vxp) - P.zmpx[kk] * xs);
             sy += K * ((px0 * cyp + px1 * vyp) - P.zmpy[kk]);
         }
         sx = wave_sum(sx); sy = wave_sum(sy);
@@ -780,14 +781,31 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
     }
     if (lane >= 16 && lane < 22) {                                 // position part, polynomials (polyval/polyder)
         const int ft = (lane - 16) / 3, ax = (lane - 16) % 3;
-        const double *co = L + P_POLY + 24 * ft + 8 * ax;
-        const int n = (int)L[P_POLY + 48 + 3 * ft + ax];
+        double co[8];
+        int n;
+        double tl = t;
+        if (P.n_seg > 0) {                                         // walking extension: segment of preview index k
+            const int kk = (k < 0) ? 0 : (k >= P.n_samples ? P.n_samples - 1 : k);
+            const double *sg = P.segs + (size_t)LMH_SEG_STRIDE * P.seg_of_sample[kk];
+            const double sc = (ax == 0 && P.xscale) ? P.xscale[inst] : 1.0;
+            tl = t - sg[0];
+#pragma unroll
+            for (int i = 0; i < 8; i++) co[i] = sg[1 + 24 * ft + 8 * ax + i] * sc;
+            n = 8;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) co[i] = L[P_POLY + 24 * ft + 8 * ax + i];
+            n = (int)L[P_POLY + 48 + 3 * ft + ax];
+        }
         double pv = 0, xp = 1;
-        for (int i = 0; i < n; i++) { pv += co[i] * xp; xp *= t; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i < n) { pv += co[i] * xp; xp *= tl; }
         double vv = 0; xp = 1;
-        if (n > 1) for (int i = 0; i < n - 1; i++) { vv += ((i + 1) * co[i + 1]) * xp; xp *= t; }
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (i < n - 1) { vv += ((i + 1) * co[i + 1]) * xp; xp *= tl; }
         double av = 0; xp = 1;
-        if (n > 2) for (int i = 0; i < n - 2; i++) { av += ((i + 1) * ((i + 2) * co[i + 2])) * xp; xp *= t; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i < n - 2) { av += ((i + 1) * ((i + 2) * co[i + 2])) * xp; xp *= tl; }
         const double pe = pv - L[P_TB + 12 * (1 + ft) + 4 * ax + 3];
         const double ve = vv - L[P_VFOOT + 6 * ft + 3 + ax];
         L[P_FREF + 6 * ft + 3 + ax] = P.kp_feet * pe + P.kd_feet * ve + av;

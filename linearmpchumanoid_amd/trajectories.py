@@ -50,33 +50,63 @@ def foot_coeff_trajectory(current_pos, des_pos, step_height, T):
     return co, n
 
 
-def walk_refs(simulation_time, time_step, num_steps=4, time_per_step=0.5, step_length=0.03,
-              ds_time=0.1, first_support=PHASE_RIGHT, settle_time=0.5):
-    """Build-defined walking references (no reference semantics beyond the conventions).
+def walk_plan(simulation_time, time_step, num_steps=4, time_per_step=0.5, ds_time=0.1, step_height=0.02,
+              settle_time=0.3, first_support=PHASE_RIGHT, foot_y=0.05):
+    """Build-defined walking references on the reference's conventions (no reference semantics: the
+    reference declares ZMP(Task, numSteps, timePerStep, simulationTime) / walkZMP but defines neither).
 
-    Piecewise-constant ZMP: y = -0.05 over the right foot, +0.05 over the left foot, 0 in
-    double support; x advances by step_length per single-support phase.  Returns
-    (zmp_x, zmp_y, phase) sampled like ZMP::stanceZMP (int((T+0.5)/dt) samples)."""
-    samples = int((simulation_time + 0.5) / time_step)
-    zx = np.zeros(samples); zy = np.zeros(samples); ph = np.full(samples, PHASE_DOUBLE, dtype=np.uint8)
-    t0 = settle_time
-    x = 0.0
+    x quantities are in units of the step length: the per-instance scale (set_xscale) turns them into
+    metres on the device.  Returns dict(zmp_x, zmp_y, phase, segs[n_seg,52], seg_of_sample):
+      * phase[k]: PHASE_DOUBLE / PHASE_RIGHT (right foot supports, left swings) / PHASE_LEFT;
+      * ZMP: support-foot position in single support, mid-point of the feet in double support;
+      * segment g = t0 | rF[3][8] | lF[3][8]: constant polynomials while a foot stands, the
+        footCoeffTrajectory() polynomials (5th order x/y, 7th order z through step_height) while it swings,
+        evaluated at t - t0.
+    Sample grid and length follow ZMP::stanceZMP: int((T + 0.5) / dt) samples, sample k <-> t = k dt."""
+    n = int((simulation_time + 0.5) / time_step)
+    zx = np.zeros(n); zy = np.zeros(n); ph = np.full(n, PHASE_DOUBLE, dtype=np.uint8)
+    sos = np.zeros(n, dtype=np.uint16)
+    segs = []
+
+    def hold(t0, xr, xl):
+        g = np.zeros(52); g[0] = t0
+        g[1 + 0] = xr; g[1 + 8] = -foot_y            # rF x, y constants (z = 0)
+        g[1 + 24 + 0] = xl; g[1 + 24 + 8] = foot_y   # lF
+        return g
+
+    def idx(t):
+        return min(n, max(0, int(round(t / time_step))))
+
+    xr = xl = 0.0
+    segs.append(hold(0.0, xr, xl))
+    cur = 0
     sup = first_support
+    t = settle_time
     for s in range(num_steps):
-        a = int(round((t0 + s * time_per_step + ds_time) / time_step))
-        b = int(round((t0 + (s + 1) * time_per_step) / time_step))
-        a, b = min(a, samples), min(b, samples)
-        ph[a:b] = sup
-        zy[a:b] = -0.05 if sup == PHASE_RIGHT else 0.05
-        zx[a:b] = x
-        d0 = int(round((t0 + s * time_per_step) / time_step))
-        zx[min(d0, samples):a] = x
-        x += step_length
+        stride = 1.0 if (s == 0 or s == num_steps - 1) else 2.0
+        t_ss0, t_ss1 = t + ds_time, t + time_per_step
+        a, b, c = idx(t), idx(t_ss0), idx(t_ss1)
+        # double support [a, b): hold segment, ZMP at the mid-point
+        segs.append(hold(t, xr, xl)); cur = len(segs) - 1
+        sos[a:b] = cur; zx[a:b] = 0.5 * (xr + xl); zy[a:b] = 0.0
+        # single support [b, c)
+        T = (c - b) * time_step
+        g = hold(b * time_step, xr, xl)
+        if sup == PHASE_RIGHT:                        # left foot swings
+            co, _ = foot_coeff_trajectory([xl, foot_y, 0.0], [xl + stride, foot_y, 0.0], step_height, T)
+            g[1 + 24:1 + 48] = co.reshape(-1); zx[b:c] = xr; zy[b:c] = -foot_y; xl += stride
+        else:
+            co, _ = foot_coeff_trajectory([xr, -foot_y, 0.0], [xr + stride, -foot_y, 0.0], step_height, T)
+            g[1:1 + 24] = co.reshape(-1); zx[b:c] = xl; zy[b:c] = foot_y; xr += stride
+        segs.append(g); cur = len(segs) - 1
+        sos[b:c] = cur; ph[b:c] = sup
         sup = PHASE_LEFT if sup == PHASE_RIGHT else PHASE_RIGHT
-    end = int(round((t0 + num_steps * time_per_step) / time_step))
-    zx[min(end, samples):] = x - step_length
-    return zx, zy, ph
+        t += time_per_step
+    a = idx(t)
+    segs.append(hold(t, xr, xl)); cur = len(segs) - 1
+    sos[a:] = cur; zx[a:] = 0.5 * (xr + xl); zy[a:] = 0.0
+    return dict(zmp_x=zx, zmp_y=zy, phase=ph, segs=np.array(segs), seg_of_sample=sos)
 
 
-__all__ = ["stance_zmp", "find_poly_coeff", "foot_coeff_trajectory", "walk_refs",
+__all__ = ["stance_zmp", "find_poly_coeff", "foot_coeff_trajectory", "walk_plan",
            "PHASE_DOUBLE", "PHASE_RIGHT", "PHASE_LEFT", "PHASE_FLIGHT"]

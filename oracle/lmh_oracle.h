@@ -34,6 +34,7 @@ extern "C" {
 #define ORC_NC 50       /* controller.hpp:89 numConstraints_  */
 #define ORC_MAXH 64     /* max preview horizon N (N+1 <= 65)  */
 #define ORC_INFTY 1.0e20 /* qpOASES::INFTY */
+#define ORC_SEG_STRIDE 52
 
 /* linkInertia.hpp:4-9 */
 typedef struct {
@@ -75,6 +76,7 @@ typedef struct {
     int faithful_rebuild;       /* 1: rebuild H = aI + b Pu'Pu every call like :89-90 */
     double xRef[3], yRef[3];
     int last_k;
+    double zmp_xscale;          /* extension: per-instance scale of the ZMP x samples (1 = reference) */
     double last_gx[ORC_MAXH + 1], last_gy[ORC_MAXH + 1];
 } orc_mpc;
 
@@ -97,6 +99,13 @@ typedef struct {
     unsigned char *phase;       /* owned, per-sample support phase (0=Double,1=Right,2=Left,3=Flight); NULL = all Double */
     double rF[3][8], lF[3][8];  /* foot polynomial coefficients, ascending powers */
     int rFn[3], lFn[3];
+    /* build-defined walking extension: piecewise foot polynomials selected by the preview index k.
+     * segment record (ORC_SEG_STRIDE doubles): t0 | rF[3][8] | lF[3][8] | pad(3); polynomials are
+     * evaluated at (t - t0); x-axis coefficients and the ZMP x samples are multiplied by xscale. */
+    int n_seg;
+    double *segs;               /* owned, [n_seg][ORC_SEG_STRIDE] */
+    unsigned short *seg_of_sample; /* owned, [n_zmp] */
+    double xscale;
     int wbc_calls_per_eval;     /* 1 (result-neutral default) or 2 (apps/offline/main.cpp:103-105) */
 } orc_controller;
 
@@ -169,6 +178,7 @@ void orc_controller_init(orc_controller *c);                          /* control
 void orc_controller_set_refs(orc_controller *c, int n, const double *zx, const double *zy,
                              const unsigned char *phase);
 void orc_controller_free(orc_controller *c);
+void orc_controller_set_segments(orc_controller *c, int n_seg, const double *segs, const unsigned short *seg_of_sample, double xscale);
 void orc_stand_step(orc_system *s, const double *q, const double *dq, double t, orc_eval *out); /* controller.cpp:48-79 */
 
 /* ---- closed loop (apps/offline/main.cpp:66-122, rk4.hpp:5-18, Clock.hpp:11) ---- */

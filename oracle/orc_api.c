@@ -250,6 +250,16 @@ void orc_sys_set_zcom(void *h, double zcom)
 {
     orc_box *b = (orc_box *)h;
     int faithful = b->sys.mpc.faithful_rebuild;
+    double zs = b->sys.mpc.zmp_xscale;
     orc_mpc_init(&b->sys.mpc, b->sys.mpc.dt, b->sys.mpc.timeHorizon, zcom);
     b->sys.mpc.faithful_rebuild = faithful;
+    b->sys.mpc.zmp_xscale = zs;
+}
+
+/* walking extension: piecewise foot polynomials + per-instance x scale (see lmh_oracle.h) */
+void orc_sys_set_segments(void *h, int n_seg, const double *segs, const unsigned short *seg_of_sample, double xscale)
+{
+    orc_box *b = (orc_box *)h;
+    orc_controller_set_segments(&b->sys.ctl, n_seg, segs, seg_of_sample, xscale);
+    b->sys.mpc.zmp_xscale = xscale;
 }

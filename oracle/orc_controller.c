@@ -34,6 +34,7 @@ void orc_controller_init(orc_controller *c)                      /* controller.c
     const double rf[9] = {0, 0, 1, 0, -1, 0, 1, 0, 0};           /* Robot.cpp:28-31 */
     memcpy(c->Rf_q0, rf, sizeof(rf));
     c->wbc_calls_per_eval = 1;
+    c->xscale = 1.0;
 }
 
 void orc_controller_set_refs(orc_controller *c, int n, const double *zx, const double *zy, const unsigned char *phase)
@@ -53,8 +54,22 @@ void orc_controller_set_refs(orc_controller *c, int n, const double *zx, const d
 
 void orc_controller_free(orc_controller *c)
 {
-    free(c->zmpX); free(c->zmpY); free(c->phase);
-    c->zmpX = c->zmpY = NULL; c->phase = NULL;
+    free(c->zmpX); free(c->zmpY); free(c->phase); free(c->segs); free(c->seg_of_sample);
+    c->zmpX = c->zmpY = NULL; c->phase = NULL; c->segs = NULL; c->seg_of_sample = NULL; c->n_seg = 0;
+}
+
+void orc_controller_set_segments(orc_controller *c, int n_seg, const double *segs, const unsigned short *seg_of_sample, double xscale)
+{
+    free(c->segs); free(c->seg_of_sample);
+    c->segs = NULL; c->seg_of_sample = NULL;
+    c->n_seg = n_seg;
+    c->xscale = xscale;
+    if (n_seg > 0) {
+        c->segs = (double *)malloc(sizeof(double) * ORC_SEG_STRIDE * (size_t)n_seg);
+        memcpy(c->segs, segs, sizeof(double) * ORC_SEG_STRIDE * (size_t)n_seg);
+        c->seg_of_sample = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)c->n_zmp);
+        memcpy(c->seg_of_sample, seg_of_sample, sizeof(unsigned short) * (size_t)c->n_zmp);
+    }
 }
 
 static void pd_joints_acc(const orc_system *s, double qppRef[ORC_NQ])    /* :296-308 */
@@ -81,7 +96,7 @@ static void pd_momentum_acc(const orc_system *s, double hGpRef[6])       /* :310
     }
 }
 
-static void pd_feet_acc(const orc_system *s, const double *JFeet, double t, double footAccRef[12])  /* :327-386 */
+static void pd_feet_acc(const orc_system *s, const double *JFeet, double t, int k, double footAccRef[12])  /* :327-386 */
 {
     const orc_gains *g = &s->ctl.gains;
     const orc_robot *r = &s->robot;
@@ -95,6 +110,17 @@ static void pd_feet_acc(const orc_system *s, const double *JFeet, double t, doub
         const double *T = r->T[frames[sfoot]];
         const double (*co)[8] = sfoot ? c->lF : c->rF;
         const int *nc = sfoot ? c->lFn : c->rFn;
+        static const int nc8[3] = {8, 8, 8};
+        double tl = t, cs[3][8];
+        if (c->n_seg > 0) {                                        /* extension: segment of preview index k */
+            int kk = (k < 0) ? 0 : (k >= c->n_zmp ? c->n_zmp - 1 : k);
+            const double *sg = c->segs + (size_t)ORC_SEG_STRIDE * c->seg_of_sample[kk];
+            tl = t - sg[0];
+            for (int a = 0; a < 3; a++)
+                for (int i = 0; i < 8; i++) cs[a][i] = sg[1 + 24 * sfoot + 8 * a + i] * ((a == 0) ? c->xscale : 1.0);
+            co = (const double (*)[8])cs;
+            nc = nc8;
+        }
         double Rf[9], err[9], aa[3], e[3];
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) Rf[a * 3 + b] = T[a * 4 + b];
@@ -106,9 +132,9 @@ static void pd_feet_acc(const orc_system *s, const double *JFeet, double t, doub
             double d1[8], d2[8];
             int n1 = orc_polyder(co[k], nc[k], d1);
             int n2 = orc_polyder(d1, n1, d2);
-            double pRef = orc_polyval(co[k], nc[k], t);
-            double vRef = orc_polyval(d1, n1, t);
-            double aRef = orc_polyval(d2, n2, t);
+            double pRef = orc_polyval(co[k], nc[k], tl);
+            double vRef = orc_polyval(d1, n1, tl);
+            double aRef = orc_polyval(d2, n2, tl);
             double posErrA = e[k];
             double posErrL = pRef - T[k * 4 + 3];
             double velErrA = 0.0 - vel[6 * sfoot + k];
@@ -156,7 +182,7 @@ static void wbc(orc_system *s, double t, const double *JFeet, int phase, orc_eva
     double *H = out->H, *gv = out->g, *A = out->A;
     pd_joints_acc(s, out->qppRef);
     pd_momentum_acc(s, out->hGpRef);
-    pd_feet_acc(s, JFeet, t, out->footAccRef);
+    pd_feet_acc(s, JFeet, t, s->mpc.last_k, out->footAccRef);
 
     double WJ[ORC_NQ], WC[6];
     for (int i = 0; i < 3; i++) { WJ[i] = g->wBasePos; WJ[3 + i] = g->wBaseAng; WC[i] = g->wCoMK; WC[3 + i] = g->wCoML; }

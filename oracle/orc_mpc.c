@@ -27,6 +27,7 @@ void orc_mpc_init(orc_mpc *m, double dt, double timeHorizon, double zCom)   /* :
     memset(m, 0, sizeof(*m));
     m->dt = dt; m->timeHorizon = timeHorizon; m->zCom = zCom;
     m->gravity = 9.81; m->alpha = 1e-3; m->beta = 1;              /* mpcLinearPendulum.hpp:46-48 */
+    m->zmp_xscale = 1.0;
     m->horizon = (int)(timeHorizon / dt);                          /* :43 */
     if (m->horizon > ORC_MAXH) m->horizon = ORC_MAXH;
     const int N = m->horizon;
@@ -68,11 +69,11 @@ static void ensure_factor(orc_mpc *m)
     free(H);
 }
 
-static double solve_axis(const orc_mpc *m, const double xk[2], const double *zmp, double *g)
+static double solve_axis(const orc_mpc *m, const double xk[2], const double *zmp, double zscale, double *g)
 {
     int n = m->horizon + 1;
     double r[LD], u[LD], Lc[LD * LD];
-    for (int i = 0; i < n; i++) r[i] = (m->Px[i * 2] * xk[0] + m->Px[i * 2 + 1] * xk[1]) - zmp[i];
+    for (int i = 0; i < n; i++) r[i] = (m->Px[i * 2] * xk[0] + m->Px[i * 2 + 1] * xk[1]) - zmp[i] * zscale;
     for (int j = 0; j < n; j++) {                /* g = beta * Pu' * r, :96-97 */
         double s = 0.0;
         for (int i = 0; i < n; i++) s += m->beta * m->Pu[i * LD + j] * r[i];
@@ -91,8 +92,8 @@ void orc_mpc_compute(orc_mpc *m, const double pos[2], const double vel[2],
     ensure_factor(m);
     int k = (int)(t / m->dt);                    /* :92 -- the only data-dependent integer */
     m->last_k = k;
-    double accx = solve_axis(m, xk, zmpX + k, m->last_gx);
-    double accy = solve_axis(m, yk, zmpY + k, m->last_gy);
+    double accx = solve_axis(m, xk, zmpX + k, m->zmp_xscale, m->last_gx);
+    double accy = solve_axis(m, yk, zmpY + k, 1.0, m->last_gy);
     double nx0 = m->A[0] * xk[0] + m->A[1] * xk[1] + m->B[0] * accx;
     double nx1 = m->A[2] * xk[0] + m->A[3] * xk[1] + m->B[1] * accx;
     double ny0 = m->A[0] * yk[0] + m->A[1] * yk[1] + m->B[0] * accy;

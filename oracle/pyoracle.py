@@ -111,6 +111,12 @@ class Oracle:
     def set_zcom(self, z):
         lib().orc_sys_set_zcom(self._h, C.c_double(z))
 
+    def set_segments(self, segs, seg_of_sample, xscale=1.0):
+        segs = np.ascontiguousarray(segs, dtype=np.float64)
+        sos = np.ascontiguousarray(seg_of_sample, dtype=np.uint16)
+        assert len(sos) == self.n_zmp and segs.shape[1] == 52
+        lib().orc_sys_set_segments(self._h, C.c_int(segs.shape[0]), _p(segs), _p(sos), C.c_double(xscale))
+
     def set_wbc_calls(self, n, faithful=False):
         lib().orc_sys_set_wbc_calls(self._h, int(n), int(faithful))
 

@@ -276,3 +276,43 @@ def test_full_size_sample_against_oracle(cfg2):
         assert status[i, 0] == r["k"][-1]
         assert rel_err(out[i, :24], r["log"][-1][:24]) < TOL_REL and rel_err(out[i, 24:36], r["log"][-1][24:]) < TOL_REL
         assert np.abs(stn[i, :60] - r["state"]).max() < 1e-8
+
+
+def test_walking_contact_switching_parity(cfg2):
+    """BASELINE config-3 ingredients at small scale: piecewise ZMP, per-sample support phase (contact
+    switching), swing-foot polynomial segments, per-instance step length.  4 instances x 700 ticks
+    (settle, double support, one single-support swing) against the oracle; k and phase bit-exact."""
+    from linearmpchumanoid_amd import trajectories
+    from oracle.pyoracle import Oracle
+    dt, N = 1e-3, 32
+    th = N * dt
+    nt = 700
+    plan = trajectories.walk_plan(2.0, dt, num_steps=2, time_per_step=0.4, ds_time=0.1, step_height=0.02, settle_time=0.15)
+    xs = np.array([0.02, 0.03, 0.04, 0.05])
+    B = len(xs)
+    ctl = make_controller(B, dt, th, cfg2["zcom"], warm_start=1)
+    ctl.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+    ctl.set_segments(plan["segs"], plan["seg_of_sample"])
+    ctl.set_xscale(xs)
+    st = ctl.new_state(cfg2["q0"], np.zeros(30), t=0.0)
+    out, status, log = ctl.rollout(st, nt, log=True)
+    torch.cuda.synchronize()
+    stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
+    assert (status[:, 2] == 0).all()
+    saw_single_support = False
+    for i in range(B):
+        o = Oracle(sim_time=2.0, dt=dt, horizon_time=th, do_ik=True)
+        o.set_zcom(cfg2["zcom"])
+        o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+        o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
+        r = o.rollout(np.concatenate([cfg2["q0"], np.zeros(30)]), 0.0, nt, log=True)
+        assert status[i, 0] == r["k"][-1]
+        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+        for tk in range(0, nt, 7):
+            ref = r["log"][tk]
+            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
+            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+            if np.abs(ref[24 + 6:24 + 12]).max() < 1e-9 and np.abs(ref[24:24 + 6]).max() > 1.0:
+                saw_single_support = True
+                assert np.abs(log[tk, i, 24 + 6:]).max() == 0.0     # swing foot carries exactly no force
+    assert saw_single_support

@@ -87,3 +87,30 @@ def test_summary_fields():
     out[:, 24 + 5] = 20.0; out[:, 24 + 11] = 32.0; out[0, 3] = -9.0
     s = sharding.make_summary(st, out, status)
     assert s[0, 7] == 9.0 and s[0, 8] == 52.0 and s[0, 14] == 4 and s[1, 14] == 32 and s[1, 13] == 1 and s[1, 11] == 7
+
+
+def test_walk_plan_is_consistent():
+    """Build-defined walking references: phases, ZMP and swing polynomials agree with each other."""
+    from linearmpchumanoid_amd.capi import PHASE_DOUBLE, PHASE_LEFT, PHASE_RIGHT
+    dt = 1e-3
+    p = trajectories.walk_plan(2.5, dt, num_steps=4, time_per_step=0.5, ds_time=0.1, step_height=0.02, settle_time=0.3)
+    n = len(p["zmp_x"])
+    assert n == int((2.5 + 0.5) / dt) and len(p["phase"]) == n and len(p["seg_of_sample"]) == n
+    assert p["seg_of_sample"].max() < len(p["segs"]) and p["segs"].shape[1] == 52
+    ph = p["phase"]
+    assert set(np.unique(ph)) == {PHASE_DOUBLE, PHASE_LEFT, PHASE_RIGHT}
+    assert (p["zmp_y"][ph == PHASE_RIGHT] == -0.05).all() and (p["zmp_y"][ph == PHASE_LEFT] == 0.05).all()
+    assert (p["zmp_y"][ph == PHASE_DOUBLE] == 0).all()
+    # swing polynomials start / end at rest on the ground and reach the step height half-way
+    for k in np.where(np.diff(ph.astype(int)) != 0)[0][:2]:
+        kk = k + 1
+        if ph[kk] == PHASE_DOUBLE:
+            continue
+        g = p["segs"][p["seg_of_sample"][kk]]
+        co = g[1 + 24:1 + 48].reshape(3, 8) if ph[kk] == PHASE_RIGHT else g[1:25].reshape(3, 8)
+        T = (np.sum(p["seg_of_sample"] == p["seg_of_sample"][kk])) * dt
+        z = lambda t: sum(co[2, i] * t ** i for i in range(8))
+        assert abs(z(0)) < 1e-9 and abs(z(T)) < 1e-9 and abs(z(T / 2) - 0.02) < 1e-9
+    # feet end side by side
+    last = p["segs"][p["seg_of_sample"][-1]]
+    assert last[1] == last[1 + 24]
