@@ -20,7 +20,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    diag = ["-DLMH_SUBSTAMPS"] if os.environ.get("LMH_DIAG") == "1" else []      # in-kernel sub-phase stamps (diagnostic build)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *diag,
            *[os.path.join(CSRC, f) for f in SOURCES], "-o", SO]
     if verbose:
         print(" ".join(cmd))

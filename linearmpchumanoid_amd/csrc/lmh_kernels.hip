@@ -134,6 +134,16 @@ enum {
 };
 
 #define LANE ((int)threadIdx.x)
+// diagnostic sub-phase stamps (s_memtime), compiled in only with -DLMH_SUBSTAMPS (LMH_DIAG=1 build): the
+// shipped kernels execute no stamp.  Only the debug kernel points g_dbg at its dump buffer.
+#ifdef LMH_SUBSTAMPS
+__shared__ double *g_dbg;
+#define SUBSTAMP(i) do { if (g_dbg && LANE == 0) g_dbg[3900 + (i)] = (double)clock64(); } while (0)
+#define SET_GDBG(p) do { if (LANE == 0) g_dbg = (p); } while (0)
+#else
+#define SUBSTAMP(i) do { } while (0)
+#define SET_GDBG(p) do { } while (0)
+#endif
 
 // (X m)[k] for X = [E' 0; B E'],  m = [ang; lin]   (generalizedFunctions.cpp:11-19); branch-free
 __device__ __forceinline__ double x_mot(const double *E, const double *Bm, const double *m, int k)
@@ -268,6 +278,7 @@ __device__ __forceinline__ void phase_fk(double *L)
         L[P_SC + 2 * lane + 1] = c;
     }
     WSYNC();
+    SUBSTAMP(0);
     for (int e = lane; e < 28 * 12; e += 64) {
         const int s = e / 12, el = e % 12, r = el >> 2, col = el & 3;
         double val;
@@ -298,6 +309,7 @@ __device__ __forceinline__ void phase_fk(double *L)
         else val = (col == 0) ? -sp : (col == 1) ? cp * sr : cp * cr;
         L[A_T + lane] = val;
     }
+    SUBSTAMP(1);
     const int c = lane / 12, el = lane % 12, r = el >> 2, col = el & 3;
     for (int s = 0; s < 8; s++) {
         WSYNC();
@@ -337,6 +349,7 @@ __device__ __forceinline__ void phase_com_x(double *L)
         const double mass = L[P_MODEL + 392];
         L[P_COM] = cx / mass; L[P_COM + 1] = cy / mass; L[P_COM + 2] = cz / mass;
     }
+    SUBSTAMP(2);
     for (int e = lane; e < 28 * 12; e += 64) {
         const int i = e / 12, el = e % 12;
         const double *Ti = L + A_T + 12 * i;
@@ -359,6 +372,7 @@ __device__ __forceinline__ void phase_com_x(double *L)
         else L[A_XP + 3 * i + (el - 9)] = val;
     }
     WSYNC();
+    SUBSTAMP(3);
     for (int e = lane; e < 28 * 9; e += 64) {
         const int i = e / 9, a = (e % 9) / 3, b = e % 3;
         const double *E = L + A_XE + 9 * i, *p = L + A_XP + 3 * i;
@@ -369,6 +383,7 @@ __device__ __forceinline__ void phase_com_x(double *L)
         L[A_XB + e] = val;
     }
     WSYNC();
+    SUBSTAMP(4);
     // persistent copies: T0, T7, T14, X0
     if (lane < 36) L[P_TB + lane] = L[A_T + 12 * ((lane < 12) ? 0 : (lane < 24) ? 7 : 14) + lane % 12];
     if (lane < 21) L[P_X0 + lane] = (lane < 9) ? L[A_XE + lane] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XB + lane - 12];
@@ -413,6 +428,7 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
             }
         }
     }
+    SUBSTAMP(5);
     {   // acceleration sweeps (with / without gravity), lanes (chain, which, k); includes the soles
         const int c = lane / 12, which = (lane % 12) / 6, k = lane % 6;
         const int base = which ? A_ACC0 : A_ACCG;
@@ -436,6 +452,7 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
         }
     }
     WSYNC();
+    SUBSTAMP(6);
     // body forces f = I a + v x* (I v), one lane per (body, which)
     if (lane < 50) {
         const int which = lane / 25, i = f_body(lane % 25);
@@ -466,6 +483,7 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
         double *fo = L + (which ? A_F0 : A_FG) + 6 * i;
         fo[0] = n0; fo[1] = n1; fo[2] = n2; fo[3] = f0; fo[4] = f1; fo[5] = f2;
     }
+    SUBSTAMP(7);
     {   // backward sweep, lanes (chain, which, k): depth 6 -> 2 accumulate into the parent
         const int c = lane / 12, which = (lane % 12) / 6, k = lane % 6;
         const int base = which ? A_F0 : A_FG;
@@ -480,6 +498,7 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
             }
         }
         WSYNC();
+        SUBSTAMP(8);
         if (lane < 12) {                                           // base, reference order head, LA, RA, LL, RL
             const int w2 = lane / 6, k2 = lane % 6, b2 = w2 ? A_F0 : A_FG;
             double acc = L[b2 + k2];
@@ -545,6 +564,7 @@ __device__ __forceinline__ void phase_crba(double *L)
         if (up) { o[0] = mo[3 * a]; o[1] = mo[3 * a + 1]; o[2] = mo[3 * a + 2]; o[3] = c0; o[4] = c1; o[5] = c2; }
         else { o[0] = -c0; o[1] = -c1; o[2] = -c2; o[3] = (a == 0) ? m : 0.0; o[4] = (a == 1) ? m : 0.0; o[5] = (a == 2) ? m : 0.0; }
     }
+    SUBSTAMP(9);
     const int ch = lane / 12, t = lane % 12, r = t >> 1, cb = t & 1;
     for (int dl = 6; dl >= 2; dl--) {                              // chain depth of the frames folded into their parents
         const int nf = (dl == 6) ? 2 : (dl >= 3) ? 4 : 5;
@@ -561,6 +581,7 @@ __device__ __forceinline__ void phase_crba(double *L)
         }
     }
     WSYNC();
+    SUBSTAMP(10);
     if (lane < 60) crba_y(L, f_root(ch), ch, r, cb);               // depth-1 frames, slots in the reference's order
     WSYNC();
     if (lane < 60) {
@@ -577,6 +598,7 @@ __device__ __forceinline__ void phase_crba(double *L)
         L[P_MTOP + 30 * (lane / 6) + lane % 6] = acc;
     }
     WSYNC();
+    SUBSTAMP(11);
     // joint columns: f = Ic_i S, walked up the chain (Dynamics.cpp:83-93); 2 lanes per joint (k<3 | k>=3)
     for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
     const int ja = lane >> 1, hf = lane & 1;
@@ -703,6 +725,7 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         L[P_AGPQP + lane] = val;
     }
     WSYNC();
+    SUBSTAMP(12);
     if (lane < 6) {                                                // h = AG vhat (fresh velocity)
         double s = 0.0;
         for (int c = 0; c < 30; c++) s += L[P_AG + 30 * lane + c] * L[P_VHN + c];
@@ -722,6 +745,7 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
     }
     WSYNC();
+    SUBSTAMP(13);
     // ---- MPC: u0 = -K (Px x_k - z[k : k+N+1])
     const int N = P.horizon;
     const int k = (int)(t / P.dt);                                 // mpcLinearPendulum.cpp:92 (fp64, same op order)
@@ -755,6 +779,7 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
     if (P.phase) { int kk = (k < 0) ? 0 : (k >= P.n_samples ? P.n_samples - 1 : k); ph = P.phase[kk]; }
     *k_out = k; *phase_out = ph;
     WSYNC();
+    SUBSTAMP(14);
     if (lane < 3) {                                                // PDMomentumAcc, controller.cpp:310-325
         const double posRef = (lane == 0) ? L[P_MPC + 2] : (lane == 1) ? L[P_MPC + 5] : zcom;
         const double velRef = (lane == 0) ? L[P_MPC + 3] : (lane == 1) ? L[P_MPC + 6] : 0.0;
@@ -1367,6 +1392,8 @@ __global__ void __launch_bounds__(64) lmh_eval_kernel(LmhDevParams P, double *st
     unsigned F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
     F = P.warm_start ? ~F : 0xFFFFFFFFu;                           // status keeps the ACTIVE mask
     int k = 0, iters = 0;
+    SET_GDBG(DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    WSYNC();
     const int flags = controller_eval(L, P, inst, t, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
     store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
     if (LANE < 30) st[60 + LANE] = L[P_V + LANE];                  // Robot::v_ <- dq (controller.cpp:59)
@@ -1386,6 +1413,7 @@ __global__ void __launch_bounds__(64) lmh_rollout_kernel(LmhDevParams P, double 
     double *st = state + (size_t)LMH_STATE_STRIDE * inst;
     load_common(L, P, inst);
     // lane i < 60 owns state component i (q | v); v_prev lives in LDS between evaluations
+    SET_GDBG(nullptr);
     double x = (lane < 60) ? st[lane] : 0.0;
     if (lane < 30) L[P_VP + lane] = st[60 + lane];
     double t = st[90];
@@ -1456,6 +1484,7 @@ __global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double
     if (mi >= n_models) return;
     const int lane = LANE;
     const double *rw = raw + (size_t)mi * 28 * LMH_LINK_STRIDE;
+    SET_GDBG(nullptr);
     for (int e = lane; e < 30; e += 64) L[P_Q + e] = 0.0;          // FK at q = 0
     load_tables(L);
     WSYNC();
@@ -1528,6 +1557,7 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
     const int inst = blockIdx.x;
     if (inst >= P.n_instances) return;
     const int lane = LANE;
+    SET_GDBG(nullptr);
     load_common(L, P, inst);
     if (lane < 30) L[P_Q + lane] = qio[30 * (size_t)inst + lane];
     WSYNC();
@@ -1688,6 +1718,7 @@ __global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P, const doubl
     __shared__ double L[LDS_DOUBLES];
     const int inst = blockIdx.x;
     if (inst >= P.n_instances) return;
+    SET_GDBG(nullptr);
     load_common(L, P, inst);
     if (LANE < 30) L[P_Q + LANE] = q[30 * (size_t)inst + LANE];
     if (LANE < 60) L[P_V + LANE] = 0.0;
