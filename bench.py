@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cold", action="store_true", help="cold-start the QP active set every evaluation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from rocprofv3 --pmc; default: the committed profiles/ summary when the workload matches it")
     return ap.parse_args()
@@ -116,8 +117,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    if os.environ.get("LMH_BENCH_DEVICE") is not None:          # rehearsal of N>1 on a one-GPU box (gloo): all ranks share a card
+        local_rank = int(os.environ["LMH_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
 
     B = args.instances
@@ -152,12 +155,14 @@ def main():
     elapsed = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl.device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # end-of-run summary: 16 f64 per instance, gathered over RCCL (the only collective)
     summary = sharding.make_summary(state, out, status)
+    if world > 1 and args.backend != "nccl":
+        summary = summary.cpu()
     gathered = sharding.gather_summaries(summary, world, rank)
     flags = int((status[:, 2] != 0).sum().item())
 
