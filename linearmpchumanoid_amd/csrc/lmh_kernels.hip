@@ -1013,14 +1013,15 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
     return flags;
 }
 
-// Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
-__device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
+// QP set-up (controller.cpp:94-132 Hessian/gradient and the equality blocks of :388-436) down to the cone
+// problem data P, qv; NU = rows of U = [AG ; J] that carry weight (15 when the angular-momentum weight is 0).
+template <int NU>
+__device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double *dbgp)
 {
     const int lane = LANE;
     int flags = 0;
     // ---- rows of U = [AG ; J] with weights Om, skipping zero-weight rows
-    const int r0 = (P.w_com_ang == 0.0) ? 3 : 0;
-    const int nU = 18 - r0;
+    constexpr int nU = NU, r0 = 18 - NU;
     const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
     const int tr = lane & 15, tq = lane >> 4;                      // MFMA result: rows tq + 4 reg, column tr
     for (int e = lane; e < nU * 30; e += 64) {
@@ -1052,7 +1053,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         auto b_bp = [&](int k, int n) { return (n < 7 && k < 30) ? L[B_BP + 7 * k + n] : 0.0; };
         const v4d cm = mfma_tile<8>(a_u, b_ud);
         const v4d vv = mfma_tile<8>(a_u, b_bp);
-        if (nU > 16) {                                             // rows/cols 16, 17 (angular-momentum weight set): plain loops
+        if constexpr (NU > 16) {                                             // rows/cols 16, 17 (angular-momentum weight set): plain loops
             for (int e = lane; e < 2 * 18; e += 64) {
                 const int r = 16 + e / 18, c = e % 18;
                 if (c <= r) {
@@ -1089,20 +1090,13 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     WSYNC();
     if (dbgp && LANE == 0) dbgp[4073] = (double)clock64();
     {   // Cm t = V for the 7 right-hand sides: row-per-lane register LDL'
-        double a[18], bb[7];
+        double a[NU], bb[7];
         const bool on = lane < nU;
 #pragma unroll
-        for (int c = 0; c < 18; c++) a[c] = (on && c <= lane) ? L[B_K + ld * lane + c] : 0.0;
+        for (int c = 0; c < NU; c++) a[c] = (on && c <= lane) ? L[B_K + ld * lane + c] : 0.0;
 #pragma unroll
         for (int r = 0; r < 7; r++) bb[r] = on ? L[B_K + ld * (nU + r) + lane] : 0.0;
-        int badw;
-        if (nU == 15) {
-            double a15[15];
-#pragma unroll
-            for (int c = 0; c < 15; c++) a15[c] = a[c];
-            badw = ldl_solve_regs<15, 7>(a15, bb, 0x7FFFu, L + B_LS);
-        } else badw = ldl_solve_regs<18, 7>(a, bb, (1u << nU) - 1u, L + B_LS);
-        if (badw) flags |= LMH_FLAG_NOT_SPD;
+        if (ldl_solve_regs<NU, 7>(a, bb, (1u << NU) - 1u, L + B_LS)) flags |= LMH_FLAG_NOT_SPD;
         if (on) {
             bb[0] -= L[B_OB + lane];                               // t' = t_g - ob in column 0
 #pragma unroll
@@ -1207,6 +1201,14 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         }
     }
     WSYNC();
+    return flags;
+}
+
+// Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
+__device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
+{
+    const int lane = LANE;
+    int flags = (P.w_com_ang == 0.0) ? qp_setup<15>(L, P, dbgp) : qp_setup<18>(L, P, dbgp);
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
     // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
     unsigned forced = 0u;
