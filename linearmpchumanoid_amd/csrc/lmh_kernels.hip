@@ -133,7 +133,16 @@ enum {
     LDS_DOUBLES = S0 + 2512
 };
 
-#define LANE ((int)threadIdx.x)
+// The lane id goes through an opaque (volatile) asm so that, in the rollout kernel, the large amount of
+// lane-derived index arithmetic is NOT hoisted out of the tick/stage loops: hoisting it costs 256 VGPR +
+// 256 AGPR + scratch spills (~100 MB of scratch traffic per launch) for no gain.
+__device__ __forceinline__ int lane_opaque()
+{
+    int l = (int)threadIdx.x;
+    asm volatile("" : "+v"(l));
+    return l;
+}
+#define LANE lane_opaque()
 // diagnostic sub-phase stamps (s_memtime), compiled in only with -DLMH_SUBSTAMPS (LMH_DIAG=1 build): the
 // shipped kernels execute no stamp.  Only the debug kernel points g_dbg at its dump buffer.
 #ifdef LMH_SUBSTAMPS
