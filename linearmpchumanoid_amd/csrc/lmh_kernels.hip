@@ -51,15 +51,21 @@ __constant__ double c_rdes[9] = {0, 0, 1, 0, -1, 0, 1, 0, 0};
 
 // ------------------------------------------------------------------ index maps (pure arithmetic:
 // a per-lane __constant__ lookup is a global load, ~500 cycles of latency at one wave per SIMD)
-__device__ __forceinline__ int f_parent(int i) { return (i == 1 || i == 8 || i == 15 || i == 20 || i == 25) ? 0 : i - 1; }   // Robot.cpp:165
-__device__ __forceinline__ int f_act(int i) { return (i == 0 || i == 7 || i == 14 || i == 27) ? 0 : (i < 7) ? i : (i < 14) ? i - 1 : i - 2; }  // Robot.cpp:172
-__device__ __forceinline__ int f_jframe(int a) { return (a < 6) ? a + 1 : (a < 12) ? a + 2 : a + 3; }
-__device__ __forceinline__ int f_jstart(int a) { return (a < 6) ? 0 : (a < 12) ? 6 : (a < 17) ? 12 : (a < 22) ? 17 : 22; }
+// All branch-free (bit masks / compares folded into adds): select chains here turn into exec-mask code.
+__device__ __forceinline__ int f_parent(int i) { return ((0x02108102u >> i) & 1u) ? 0 : i - 1; }   // Robot.cpp:165 (roots 1,8,15,20,25)
+__device__ __forceinline__ int f_act(int i)                                                         // Robot.cpp:172
+{
+    const int a = i - (int)(i > 7) - (int)(i > 14);
+    return ((0x08004081u >> i) & 1u) ? 0 : a;                       // frames 0, 7, 14, 27 carry no joint
+}
+__device__ __forceinline__ int f_jframe(int a) { return a + 1 + (int)(a >= 6) + (int)(a >= 12); }
+__device__ __forceinline__ int f_jstart(int a) { return 6 * (int)(a >= 6) + 6 * (int)(a >= 12) + 5 * (int)(a >= 17) + 5 * (int)(a >= 22); }
 __device__ __forceinline__ int f_jdepth(int a) { return a - f_jstart(a) + 1; }
-__device__ __forceinline__ int f_body(int b) { return (b < 7) ? b : (b < 13) ? b + 1 : b + 2; }
-__device__ __forceinline__ int f_chain_base(int c) { return (c == 0) ? 1 : (c == 1) ? 8 : (c == 2) ? 15 : (c == 3) ? 20 : 25; }
-__device__ __forceinline__ int f_chain_len(int c) { return (c < 2) ? 7 : (c < 4) ? 5 : 3; }
+__device__ __forceinline__ int f_body(int b) { return b + (int)(b >= 7) + (int)(b >= 13); }
+__device__ __forceinline__ int f_chain_base(int c) { return 1 + 7 * (int)(c >= 1) + 7 * (int)(c >= 2) + 5 * (int)(c >= 3) + 5 * (int)(c >= 4); }
+__device__ __forceinline__ int f_chain_len(int c) { return 7 - 2 * (int)(c >= 2) - 2 * (int)(c >= 4); }
 __device__ __forceinline__ int f_chain(int c, int d) { return (d < f_chain_len(c)) ? f_chain_base(c) + d : -1; }
+__device__ __forceinline__ int f_root(int r) { return 25 - 5 * (int)(r >= 1) - 5 * (int)(r >= 2) - 7 * (int)(r >= 3) - 7 * (int)(r >= 4); }  // head, LA, RA, LL, RL
 // FK schedule (Robot.cpp:120-158): chain c, step s -> dst / src T slot, local-transform slot
 __device__ __forceinline__ void fk_sched(int c, int s, int *dst, int *src, int *loc)
 {
@@ -82,7 +88,6 @@ __device__ __forceinline__ double qdes_of(int i)
     return (i == 0) ? -0.0185 : (i == 2) ? 0.282 : (i == 8 || i == 14) ? -0.5 : (i == 9 || i == 15) ? 0.8
          : (i == 10 || i == 16) ? -0.3 : (i == 18) ? 1.6 : (i == 23) ? -1.6 : 0.0;
 }
-__device__ __forceinline__ int f_root(int r) { return (r == 0) ? 25 : (r == 1) ? 20 : (r == 2) ? 15 : (r == 3) ? 8 : 1; }  // reference order: head, LA, RA, LL, RL
 
 // ------------------------------------------------------------------ LDS map (doubles)
 enum {
