@@ -70,17 +70,17 @@ __device__ __forceinline__ int f_root(int r) { return 25 - 5 * (int)(r >= 1) - 5
 __device__ __forceinline__ void fk_sched(int c, int s, int *dst, int *src, int *loc)
 {
     const int base = f_chain_base(c);
-    if (c < 2) {                        // legs: T0*aux, six joints, sole
-        if (s == 0) { *dst = 28 + c; *src = 0; *loc = 25 + c; }
-        else if (s < 7) { *dst = base + s - 1; *src = (s == 1) ? 28 + c : base + s - 2; *loc = 6 * c + s - 1; }
-        else { *dst = base + 6; *src = base + 5; *loc = 27; }
-    } else if (c < 4) {                 // arms
-        if (s < 5) { *dst = base + s; *src = (s == 0) ? 0 : base + s - 1; *loc = 12 + 5 * (c - 2) + s; }
-        else *dst = -1;
-    } else {                            // head (+ extra head frame)
-        if (s < 3) { *dst = 25 + s; *src = (s == 0) ? 0 : 24 + s; *loc = 22 + s; }
-        else *dst = -1;
-    }
+    const bool leg = c < 2, arm = (c >= 2) && (c < 4);
+    // legs: step 0 = T0*aux (slots 28/29), steps 1..6 joints, step 7 sole; arms: steps 0..4; head: steps 0..2
+    const int d_leg = (s == 0) ? 28 + c : (s < 7) ? base + s - 1 : base + 6;
+    const int s_leg = (s == 0) ? 0 : (s == 1) ? 28 + c : (s < 7) ? base + s - 2 : base + 5;
+    const int l_leg = (s == 0) ? 25 + c : (s < 7) ? 6 * c + s - 1 : 27;
+    const int d_oth = base + s, s_oth = (s == 0) ? 0 : base + s - 1;
+    const int l_oth = arm ? 12 + 5 * (c - 2) + s : 22 + s;
+    const bool on = leg || (arm && s < 5) || (c == 4 && s < 3);
+    *dst = on ? (leg ? d_leg : d_oth) : -1;
+    *src = leg ? s_leg : s_oth;
+    *loc = leg ? l_leg : l_oth;
 }
 // Robot::desiredPosture (Robot.cpp:253-262)
 __device__ __forceinline__ double qdes_of(int i)
@@ -693,13 +693,24 @@ __device__ __forceinline__ void phase_jacobian(double *L)
     WSYNC();
 }
 
+// Masked LDS load without control flow: the load is always issued (from a clamped, valid address) and
+// the value is zeroed by a select; `cond ? L[i] : 0.0` would become exec-mask branching.
+__device__ __forceinline__ double ldz(const double *L, bool cond, int idx_if, int idx_safe = 0)
+{
+    const double v = L[cond ? idx_if : idx_safe];
+    return cond ? v : 0.0;
+}
+#define IMIN(a, b) (((a) < (b)) ? (a) : (b))
+
 // J[row][col] of the dense 12 x 30 feet Jacobian from the compact store
 __device__ __forceinline__ double jdense(const double *L, int row, int col)
 {
-    const int ft = row / 6, rr = row % 6;
-    if (col < 6) return L[P_JC + 72 * ft + 12 * rr + col];
-    const int j = col - 6 - 6 * ft;
-    return (j >= 0 && j < 6) ? L[P_JC + 72 * ft + 12 * rr + 6 + j] : 0.0;
+    const int ft = (int)(row >= 6), rr = row - 6 * ft;
+    const int j = col - 6 - 6 * ft;                                // leg-joint column of this foot
+    const bool base = col < 6, leg = (j >= 0) && (j < 6);
+    const int cc = base ? col : (leg ? 6 + j : 0);
+    const double v = L[P_JC + 72 * ft + 12 * rr + cc];
+    return (base || leg) ? v : 0.0;
 }
 
 // Dynamics::centroidalMatrixAndBias (Dynamics.cpp:103-121), Robot::computeComMomentum
@@ -1062,9 +1073,9 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     // ---- Cm = Om^-1 + U D^-1 U'  and  V = U bp'  on the matrix cores (K = 30 padded to 32)
     const int ld = 19;
     {
-        auto a_u = [&](int m, int k) { return (m < nU && k < 30) ? L[B_U + 30 * m + k] : 0.0; };
-        auto b_ud = [&](int k, int n) { return (n < nU && k < 30) ? L[B_U + 30 * n + k] * ((k < 3) ? idp : (k < 6) ? ida : idj) : 0.0; };
-        auto b_bp = [&](int k, int n) { return (n < 7 && k < 30) ? L[B_BP + 7 * k + n] : 0.0; };
+        auto a_u = [&](int m, int k) { return ldz(L, m < nU && k < 30, B_U + 30 * m + k, B_U); };
+        auto b_ud = [&](int k, int n) { return ldz(L, n < nU && k < 30, B_U + 30 * n + k, B_U) * ((k < 3) ? idp : (k < 6) ? ida : idj); };
+        auto b_bp = [&](int k, int n) { return ldz(L, n < 7 && k < 30, B_BP + 7 * k + n, B_BP); };
         const v4d cm = mfma_tile<8>(a_u, b_ud);
         const v4d vv = mfma_tile<8>(a_u, b_bp);
         if constexpr (NU > 16) {                                             // rows/cols 16, 17 (angular-momentum weight set): plain loops
@@ -1121,10 +1132,10 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
     // ---- Y = bp' - D^-1 U' t'   (30 x 7; two row tiles, K = nU padded to 20)
     {
-        auto b_t = [&](int k, int n) { return (k < nU && n < 7) ? L[B_K + ld * (nU + n) + k] : 0.0; };
+        auto b_t = [&](int k, int n) { return ldz(L, k < nU && n < 7, B_K + ld * (nU + n) + k, B_K); };
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
-            auto a_ut = [&](int m, int k) { const int i = 16 * mt + m; return (i < 30 && k < nU) ? L[B_U + 30 * k + i] : 0.0; };
+            auto a_ut = [&](int m, int k) { const int i = 16 * mt + m; return ldz(L, i < 30 && k < nU, B_U + 30 * k + i, B_U); };
             const v4d yy = mfma_tile<5>(a_ut, b_t);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -1137,8 +1148,8 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     if (dbgp && LANE == 0) dbgp[4010] = (double)clock64();
     // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g  (one tile, K = 30 padded to 32); Si = S^-1
     {
-        auto a_m = [&](int m, int k) { return (m < 6 && k < 30) ? L[P_MTOP + 30 * m + k] : 0.0; };
-        auto b_y = [&](int k, int n) { return (n < 7 && k < 30) ? L[P_Y + 7 * k + n] : 0.0; };
+        auto a_m = [&](int m, int k) { return ldz(L, m < 6 && k < 30, P_MTOP + 30 * m + k, P_MTOP); };
+        auto b_y = [&](int k, int n) { return ldz(L, n < 7 && k < 30, P_Y + 7 * k + n, P_Y); };
         const v4d sy = mfma_tile<8>(a_m, b_y);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -1161,16 +1172,16 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     WSYNC();
     // ---- T1 = Jb Si (12x6);  [W | h] = [w_force I + T1 Jb' | T1 d]   (K = 6 padded to 8)
     {
-        auto a_jb = [&](int m, int k) { return (m < 12 && k < 6) ? jdense(L, m, k) : 0.0; };
-        auto b_si = [&](int k, int n) { return (k < 6 && n < 6) ? L[P_SI + 6 * k + n] : 0.0; };
+        auto a_jb = [&](int m, int k) { const bool ok = m < 12 && k < 6; const double v = jdense(L, ok ? m : 0, ok ? k : 0); return ok ? v : 0.0; };
+        auto b_si = [&](int k, int n) { return ldz(L, k < 6 && n < 6, P_SI + 6 * k + n, P_SI); };
         const v4d t1 = mfma_tile<2>(a_jb, b_si);
 #pragma unroll
         for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12 && tr < 6) L[B_T1 + 6 * row + tr] = t1[g]; }
     }
     WSYNC();
     {
-        auto a_t1 = [&](int m, int k) { return (m < 12 && k < 6) ? L[B_T1 + 6 * m + k] : 0.0; };
-        auto b_jd = [&](int k, int n) { return (k >= 6) ? 0.0 : (n < 12) ? jdense(L, n, k) : (n == 12) ? L[P_D6 + k] : 0.0; };
+        auto a_t1 = [&](int m, int k) { return ldz(L, m < 12 && k < 6, B_T1 + 6 * m + k, B_T1); };
+        auto b_jd = [&](int k, int n) { const bool kin = k < 6; const double vj = jdense(L, (n < 12) ? n : 0, kin ? k : 0); const double vd = L[P_D6 + (kin ? k : 0)]; return !kin ? 0.0 : (n < 12) ? vj : (n == 12) ? vd : 0.0; };
         const v4d ww = mfma_tile<2>(a_t1, b_jd);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -1184,10 +1195,10 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     // ---- cone QP data: WG = W G (12 x 32), Pm = G' WG + eps I (32 x 32), qv = G' h ; G[k][j] is the
     //      generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
     {
-        auto a_w = [&](int m, int k) { return (m < 12 && k < 12) ? L[P_W + 12 * m + k] : 0.0; };
+        auto a_w = [&](int m, int k) { return ldz(L, m < 12 && k < 12, P_W + 12 * m + k, P_W); };
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            auto b_g = [&](int k, int n) { const int kk = k - 6 * nt; return (kk >= 0 && kk < 6) ? L[P_GCOL + 6 * n + kk] : 0.0; };
+            auto b_g = [&](int k, int n) { const int kk = k - 6 * nt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * n + kk, P_GCOL); };
             const v4d wg = mfma_tile<3>(a_w, b_g);
 #pragma unroll
             for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12) L[C_WG + 32 * row + 16 * nt + tr] = wg[g]; }
@@ -1202,10 +1213,10 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     WSYNC();
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
-        auto a_gt = [&](int m, int k) { const int kk = k - 6 * mt; return (kk >= 0 && kk < 6) ? L[P_GCOL + 6 * m + kk] : 0.0; };
+        auto a_gt = [&](int m, int k) { const int kk = k - 6 * mt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * m + kk, P_GCOL); };
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            auto b_wg = [&](int k, int n) { return (k < 12) ? L[C_WG + 32 * k + 16 * nt + n] : 0.0; };
+            auto b_wg = [&](int k, int n) { return ldz(L, k < 12, C_WG + 32 * k + 16 * nt + n, C_WG); };
             const v4d pp = mfma_tile<3>(a_gt, b_wg);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
