@@ -15,7 +15,7 @@
 
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s);
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
-extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, hipStream_t s);
+extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s);
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s);
 extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const double *target, int32_t *iters, hipStream_t s);
 
@@ -174,6 +174,40 @@ static void build_gcol(double mu, double *g /*[16][6] (one foot; both feet are i
         }
 }
 
+// Local-transform coefficient table: entry e = 12 slot + 4 row + col of slot's 3x4 transform equals
+// c0 + c1 cos(theta_slot) + c2 sin(theta_slot).  Slots 0..24 are the Khalil modified-DH transforms of
+// matTrans (src/Robot.cpp:176-223; tables :180-196) with the shoulder / head offsets of :134,143,152 folded
+// into the translations of slots 12, 17, 22; slots 25..27 are auxT01, auxT09 (0.7071 literals, :92-103) and
+// the sole offset (:106-117).  cos/sin(alpha) are libm's values for the reference's pi literal.
+static void build_lcoef(double *t /*[336][3]*/)
+{
+    const double pi = 3.14159265358979323846, h = pi / 2;
+    const double r[25] = {-0.07071, 0, 0, 0, 0, 0, 0.07071, 0, 0, 0, 0, 0, 0, 0, 0.105, 0, 0.05595, 0, 0, 0.105, 0, 0.05595, 0, 0, 0};
+    const double d[25] = {0, 0, 0, -0.1, -0.1029, 0, 0, 0, 0, -0.1, -0.1029, 0, 0, 0, -0.015, 0, 0, 0, 0, -0.015, 0, 0, 0, 0, 0.030};
+    const double al[25] = {0, h, h, 0, 0, -h, -h, -h, h, 0, 0, -h, -h, h, h, -h, h, h, h, h, -h, h, 0, -h, 0};
+    const double aux[3][12] = {{0, -1, 0, 0, 0.7071, 0, 0.7071, 0, -0.7071, 0, 0.7071, 0},
+                               {1, 0, 0, 0, 0, 0.7071, 0.7071, 0, 0, -0.7071, 0.7071, 0},
+                               {1, 0, 0, -0.0452, 0, 1, 0, 0, 0, 0, 1, 0}};
+    std::memset(t, 0, sizeof(double) * 3 * 336);
+    for (int s = 0; s < 25; s++) {
+        const double ca = std::cos(al[s]), sa = std::sin(al[s]);
+        double *e = t + 3 * 12 * s;
+        // row 0: ct, -st, 0, d
+        e[3 * 0 + 1] = 1.0; e[3 * 1 + 2] = -1.0; e[3 * 3 + 0] = d[s];
+        // row 1: ca st, ca ct, -sa, -r sa
+        e[3 * 4 + 2] = ca; e[3 * 5 + 1] = ca; e[3 * 6 + 0] = -sa; e[3 * 7 + 0] = -r[s] * sa;
+        // row 2: sa st, sa ct, ca, r ca
+        e[3 * 8 + 2] = sa; e[3 * 9 + 1] = sa; e[3 * 10 + 0] = ca; e[3 * 11 + 0] = r[s] * ca;
+        if (s == 12 || s == 17 || s == 22) {
+            e[3 * 3 + 0] = e[3 * 3 + 0] + 0.0;
+            e[3 * 7 + 0] = e[3 * 7 + 0] + ((s == 12) ? -0.098 : (s == 17) ? 0.098 : 0.0);
+            e[3 * 11 + 0] = e[3 * 11 + 0] + ((s == 22) ? 0.1615 : 0.13591);
+        }
+    }
+    for (int s = 25; s < 28; s++)
+        for (int k = 0; k < 12; k++) t[3 * (12 * s + k)] = aux[s - 25][k];
+}
+
 static void fill_params(lmh_handle *h)
 {
     LmhDevParams &P = h->P;
@@ -220,8 +254,9 @@ extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lm
     h->N = (int)(cfg->time_horizon / cfg->dt);                      // mpcLinearPendulum.cpp:43
     if (h->N < 1 || h->N > LMH_MAX_HORIZON) { delete h; return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/dt must be in [1, 64]"); }
     std::memset(&h->P, 0, sizeof(h->P));
-    double g[16 * 6 + 36 + 96];
+    double g[16 * 6 + 36 + 96 + 3 * 336];
     build_gcol(cfg->mu, g);
+    build_lcoef(g + 228);
     HIPCHK(hipMalloc(&h->d_gcol, sizeof(g)));
     HIPCHK(hipMemcpy(h->d_gcol, g, sizeof(g), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&h->d_state, sizeof(double) * LMH_STATE_STRIDE * (size_t)n_instances));
@@ -273,7 +308,7 @@ extern "C" int lmh_set_model(lmh_handle *h, const double *raw, int n_models)
     HIPCHK(hipMalloc(&h->d_raw, rawb));
     HIPCHK(hipMalloc(&h->d_model, sizeof(double) * LMH_MODEL_STRIDE * (size_t)n_models));
     HIPCHK(hipMemcpy(h->d_raw, raw, rawb, hipMemcpyHostToDevice));
-    lmh_launch_model(h->d_raw, h->d_model, n_models, nullptr);
+    lmh_launch_model(h->d_raw, h->d_model, n_models, h->d_gcol + 228, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     h->n_models = n_models;

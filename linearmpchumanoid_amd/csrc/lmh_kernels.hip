@@ -280,7 +280,7 @@ __device__ __forceinline__ v4d mfma_tile(FA a_of, FB b_of)
 // ============================================================================ kinematics
 // Robot::forwardKinematics + matTrans + eulerAnglesToSO3 (Robot.cpp:45-160,176-223,
 // generalizedFunctions.cpp:52-72).  Reads L[P_Q], writes A_T (30 x 3x4) and L[P_SC].
-__device__ __forceinline__ void phase_fk(double *L)
+__device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
 {
     const int lane = LANE;
     if (lane < 28) {
@@ -293,25 +293,26 @@ __device__ __forceinline__ void phase_fk(double *L)
     }
     WSYNC();
     SUBSTAMP(0);
-    for (int e = lane; e < 28 * 12; e += 64) {
-        const int s = e / 12, el = e % 12, r = el >> 2, col = el & 3;
-        double val;
-        if (s < 25) {
-            const double st = L[P_SC + 2 * s], ct = L[P_SC + 2 * s + 1];
-            const double ca = L[P_TAB + 50 + s], sa = L[P_TAB + 75 + s], dd = L[P_TAB + 25 + s], rr = L[P_TAB + s];
-            if (r == 0) val = (col == 0) ? ct : (col == 1) ? -st : (col == 2) ? 0.0 : dd;
-            else if (r == 1) val = (col == 0) ? ca * st : (col == 1) ? ca * ct : (col == 2) ? -sa : -rr * sa;
-            else val = (col == 0) ? sa * st : (col == 1) ? sa * ct : (col == 2) ? ca : rr * ca;
-            if (col == 3 && (s == 12 || s == 17 || s == 22)) {
-                const int o = (s == 12) ? 0 : (s == 17) ? 1 : 2;
-                if (r == 0) val = val + 0.0;
-                else if (r == 1) val = val + ((o == 0) ? -0.098 : (o == 1) ? 0.098 : 0.0);      // Robot.cpp:134,143,152
-                else val = val + ((o == 2) ? 0.1615 : 0.13591);
-            }
-        } else {
-            val = L[P_TAB + 124 + 12 * (s - 25) + el];
+    // local transforms (Khalil DH, Robot.cpp:200-214 + the fixed transforms / offsets of :92-154): every entry is
+    // c0 + c1 cos(theta) + c2 sin(theta) with model constants (c0, c1, c2) tabulated once on the host
+    // (lcoef, L2-resident); the zero / one coefficients make the fused form bit-identical to the products.
+    {
+        double c0[6], c1[6], c2[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            const int e = lane + 64 * u;
+            const double *cf = lcoef + 3 * ((e < 336) ? e : 0);
+            c0[u] = cf[0]; c1[u] = cf[1]; c2[u] = cf[2];
         }
-        L[A_LC + e] = val;
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            const int e = lane + 64 * u;
+            if (e < 336) {
+                const int sl = e / 12;
+                const int ss = (sl < 25) ? sl : 24;                // slots 25..27 are constants (c1 = c2 = 0)
+                L[A_LC + e] = fma(c2[u], L[P_SC + 2 * ss], fma(c1[u], L[P_SC + 2 * ss + 1], c0[u]));
+            }
+        }
     }
     if (lane < 12) {                                               // T0 = [R(rpy) p]
         const int r = lane >> 2, col = lane & 3;
@@ -364,26 +365,20 @@ __device__ __forceinline__ void phase_com_x(double *L)
         L[P_COM] = cx / mass; L[P_COM + 1] = cy / mass; L[P_COM + 2] = cz / mass;
     }
     SUBSTAMP(2);
-    for (int e = lane; e < 28 * 12; e += 64) {
-        const int i = e / 12, el = e % 12;
-        const double *Ti = L + A_T + 12 * i;
-        double val;
-        if (i == 0) {
-            val = (el < 9) ? Ti[(el / 3) * 4 + el % 3] : Ti[(el - 9) * 4 + 3];
-        } else {
-            const double *Tp = L + A_T + 12 * f_parent(i);
-            if (el < 9) {
-                const int a = el / 3, b = el % 3;
-                val = Tp[a] * Ti[b] + Tp[4 + a] * Ti[4 + b] + Tp[8 + a] * Ti[8 + b];
-            } else {
-                const int a = el - 9;
-                const double pa = Tp[a] * Ti[3] + Tp[4 + a] * Ti[7] + Tp[8 + a] * Ti[11];
-                const double pb = (-Tp[a]) * Tp[3] + (-Tp[4 + a]) * Tp[7] + (-Tp[8 + a]) * Tp[11];
-                val = pa + pb;
-            }
-        }
-        if (el < 9) L[A_XE + 9 * i + el] = val;
-        else L[A_XP + 3 * i + (el - 9)] = val;
+    for (int e = lane; e < 27 * 12; e += 64) {                     // frames 1..27: E = Rp' Ri, p = Rp' pi + (-Rp') pp
+        const int i = 1 + e / 12, el = e % 12;
+        const bool isE = el < 9;
+        const int a = isE ? el / 3 : el - 9, col = isE ? el % 3 : 3;
+        const double *Ti = L + A_T + 12 * i + col, *Tp = L + A_T + 12 * f_parent(i);
+        const double t0 = Tp[a], t1 = Tp[4 + a], t2 = Tp[8 + a];
+        const double s1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
+        const double s2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
+        L[(isE ? A_XE + 9 * i + el : A_XP + 3 * i + (el - 9))] = isE ? s1 : s1 + s2;
+    }
+    if (lane < 12) {                                               // frame 0: E = R0, p = p0
+        const double *T0 = L + A_T;
+        if (lane < 9) L[A_XE + lane] = T0[(lane / 3) * 4 + lane % 3];
+        else L[A_XP + (lane - 9)] = T0[(lane - 9) * 4 + 3];
     }
     WSYNC();
     SUBSTAMP(3);
@@ -1314,7 +1309,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
 #define STAMP(i) do { if (dbg && LANE == 0) dbg[4000 + (i)] = (double)clock64(); } while (0)
     STAMP(0);
-    phase_fk(L);
+    phase_fk(L, P.gcol + 228);
     STAMP(1);
     phase_com_x(L);
     STAMP(2);
@@ -1504,7 +1499,7 @@ __global__ void __launch_bounds__(64) lmh_rollout_kernel(LmhDevParams P, double 
 
 // Robot::Robot model preparation (Robot.cpp:14-22) + Dynamics::spatialInertiaMatrix pieces
 // (Dynamics.cpp:4-13): raw [28][13] -> device model record.
-__global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double *model, int n_models)
+__global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double *model, int n_models, const double *lcoef)
 {
     __shared__ double L[LDS_DOUBLES];
     const int mi = blockIdx.x;
@@ -1515,7 +1510,7 @@ __global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double
     for (int e = lane; e < 30; e += 64) L[P_Q + e] = 0.0;          // FK at q = 0
     load_tables(L);
     WSYNC();
-    phase_fk(L);
+    phase_fk(L, lcoef);
     double mloc = 0.0;
     if (lane < 28) {
         const double *T = L + A_T + 12 * lane, *lk = rw + LMH_LINK_STRIDE * lane;
@@ -1597,7 +1592,7 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
     const double mass = L[P_MODEL + 392];
     int iter = 0;
     for (;;) {
-        phase_fk(L);
+        phase_fk(L, P.gcol + 228);
         phase_com_x(L);
         phase_jacobian(L);
         // operationalState (:54-70)
@@ -1750,7 +1745,7 @@ __global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P, const doubl
     if (LANE < 30) L[P_Q + LANE] = q[30 * (size_t)inst + LANE];
     if (LANE < 60) L[P_V + LANE] = 0.0;
     WSYNC();
-    phase_fk(L);
+    phase_fk(L, P.gcol + 228);
     phase_com_x(L);
     if (LANE < 3) com[3 * (size_t)inst + LANE] = L[P_COM + LANE];
 }
@@ -1768,7 +1763,7 @@ extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double 
 {
     hipLaunchKernelGGL(lmh_rollout_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, log, n_ticks);
 }
-extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, hipStream_t s)
+extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s)
 {
-    hipLaunchKernelGGL(lmh_model_kernel, dim3(n_models), dim3(64), 0, s, raw, model, n_models);
+    hipLaunchKernelGGL(lmh_model_kernel, dim3(n_models), dim3(64), 0, s, raw, model, n_models, lcoef);
 }
