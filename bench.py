@@ -45,12 +45,11 @@ def parse():
     return ap.parse_args()
 
 
-def ik_posture():
-    """IK start posture of apps/offline (CoM (-0.02,0,0.26)): committed fixture (data)."""
-    import json as _j
-    with open(os.path.join(ROOT, "tests", "golden", "ik_posture.json")) as f:
-        d = _j.load(f)
-    return np.array(d["q"], dtype=np.float64), float(d["z_com"])
+def ik_posture(device=0):
+    """IK start posture of apps/offline (feet (0,-/+0.05,0), CoM (-0.02,0,0.26)) and the LIPM height, computed by the
+    product's own IK kernel (Kinematics::compute on the GPU), as apps/offline/main.cpp:24-39 does at start-up."""
+    from linearmpchumanoid_amd.controller import ik_start_posture
+    return ik_start_posture(device)
 
 
 def perturbed_velocities(first, count, seed=20260001):
@@ -125,7 +124,7 @@ def main():
 
     B = args.instances
     first, count = sharding.shard_range(B * world, world, rank)
-    q0, zcom = ik_posture()
+    q0, zcom = ik_posture(local_rank)
     th = args.horizon * args.dt
     cfg = default_config(dt=args.dt, time_horizon=th, z_com=zcom, warm_start=0 if args.cold else 1)
     ctl = BatchedController(count, cfg, device=local_rank)

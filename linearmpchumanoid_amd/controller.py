@@ -33,6 +33,30 @@ def nominal_links():
     return raw
 
 
+def initial_configuration():
+    """initialConfiguration() of the reference (src/Robot.cpp:242-251): posture the IK starts from."""
+    return np.array([-0.0185, 0, 0.282, 0, 0, 0,
+                     0, 0, -0.5, 0.8, -0.3, 0,
+                     0, 0, -0.5, 0.8, -0.3, 0,
+                     1.6, 0, 0, 0, 0,
+                     -1.6, 0, 0, 0, 0,
+                     0, 0], dtype=np.float64)
+
+
+def ik_start_posture(device=0, com_target=(-0.02, 0.0, 0.26)):
+    """apps/offline/main.cpp:24-39 on the GPU: IK to feet (0,-/+0.05,0) and the CoM target; returns (q[30], z_com)
+    where z_com = Robot::getCoM()(2) after the IK (the Mpc3dLip constructor argument)."""
+    ctl = BatchedController(1, default_config(), device=device)
+    q = torch.as_tensor(initial_configuration()[None, :]).to(ctl.device)
+    q, iters = ctl.ik(q, com_target=com_target)
+    com = torch.zeros((1, 3), dtype=torch.float64, device=ctl.device)
+    check(capi.lib().lmh_robot_com(ctl._h, _dev_ptr(q), _dev_ptr(com), ctl._stream()))
+    torch.cuda.synchronize(ctl.device)
+    out = q.cpu().numpy()[0].copy(), float(com.cpu().numpy()[0, 2])
+    ctl.close()
+    return out
+
+
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
