@@ -1,11 +1,11 @@
 // lmh_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the batched NAO controller.
 //
-// ONE WAVEFRONT (64 lanes) OWNS ONE ROBOT INSTANCE.  A workgroup is exactly one wave, so
-// every "barrier" below is a wave-level fence (hipcc lowers __syncthreads() of a 64-thread
-// workgroup to a wave barrier); all per-instance working data (kinematic tree, spatial
-// inertias, mass matrix, Jacobians, QP blocks) lives in ~38 KB of LDS (4 instances per CU),
-// HBM is touched only for the 768-B state record in, the 576-B result out and the shared
-// read-only tables (model, MPC gain row, ZMP window) which stay L2-resident.
+// ONE WAVEFRONT (64 lanes) OWNS ONE ROBOT INSTANCE.  A workgroup is exactly one wave, so every
+// "barrier" below is a wave-level fence (hipcc lowers __syncthreads() of a 64-thread workgroup to a
+// wave barrier); all per-instance working data (kinematic tree, spatial inertias, mass matrix,
+// Jacobians, QP blocks) lives in ~40 KB of LDS (4 instances per CU = one wave per SIMD at B = 1024).
+// HBM is touched only for the 768-B state record in, the 640-B result out, the optional 288-B log per
+// tick and the shared read-only tables (model, MPC gain row, ZMP window) which stay L2-resident.
 //
 // What is evaluated (reference file:line each block follows is cited inline):
 //   Robot::updateState  -> FK, CoM, parent-relative Pluecker transforms    src/Robot.cpp
@@ -16,11 +16,14 @@
 //   rk4Step(dynamics)   -> closed loop                                     rk4.hpp, apps/offline/main.cpp
 //
 // The QP (74 variables, 18 equalities, 32 bounds) is solved EXACTLY but not densely:
-//   * H_aa = D + U' Om U (diagonal + rank<=18)  -> Woodbury with an 18x18 Cholesky,
+//   * H_aa = D + U' Om U (diagonal + rank 15..18)  -> Woodbury with a 15x15 (18x18) SPD solve,
 //   * the 6 floating-base rows are eliminated through the 6x6 Schur complement S,
 //   * w = G c is substituted, leaving a 32-variable bound-constrained strictly convex QP
-//     min 1/2 c'(G'WG + eps I)c - (G'h)'c, c >= 0, solved by block principal pivoting
-//     (finite, exact at termination; warm-startable from the previous active set).
+//     min 1/2 c'(G'WG + eps I)c - (G'h)'c, c >= 0: a 12x12 push-through solve when every coefficient
+//     is free, otherwise block principal pivoting from the previous active set with a Lawson-Hanson
+//     pass as the finite fall-back.
+//   * every SPD solve is a register-resident LDL' (row per lane, v_readlane pivot broadcast); the small
+//     dense products of the set-up run as v_mfma_f64_16x16x4_f64 tiles.
 // The minimiser is unique (H is SPD), so this equals what qpOASES returns in the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,21 +33,11 @@
 #define WSYNC() __syncthreads()
 
 // ------------------------------------------------------------------ constant tables
-// Khalil modified-DH tables, Robot.cpp:180-196.  cos/sin(alpha) are the values libm returns for
-// the reference's literal pi (cos(+-pi/2) = 6.123233995736766e-17, kept: SURVEY appendix A3).
-#define CPI2 6.123233995736766e-17
-__constant__ double c_dh_r[25] = {-0.07071, 0, 0, 0, 0, 0, 0.07071, 0, 0, 0, 0, 0, 0, 0, 0.105, 0, 0.05595, 0, 0, 0.105, 0, 0.05595, 0, 0, 0};
-__constant__ double c_dh_d[25] = {0, 0, 0, -0.1, -0.1029, 0, 0, 0, 0, -0.1, -0.1029, 0, 0, 0, -0.015, 0, 0, 0, 0, -0.015, 0, 0, 0, 0, 0.030};
-__constant__ double c_dh_ca[25] = {1, CPI2, CPI2, 1, 1, CPI2, CPI2, CPI2, CPI2, 1, 1, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, CPI2, 1, CPI2, 1};
-__constant__ double c_dh_sa[25] = {0, 1, 1, 0, 0, -1, -1, -1, 1, 0, 0, -1, -1, 1, 1, -1, 1, 1, 1, 1, -1, 1, 0, -1, 0};
+#define CPI2 6.123233995736766e-17   // libm's cos(-pi/2) for the reference's pi literal (theta[24], Robot.cpp:87)
 // theta offsets, Robot.cpp:59-87, as multiples of the reference's pi literal
 #define RPI 3.14159265358979323846
 __constant__ double c_dh_off[24] = {0, (3.0 / 4) * RPI, 0, 0, 0, 0, -(1.0 / 2) * RPI, (1.0 / 4) * RPI, 0, 0, 0, 0,
                                     0, (1.0 / 2) * RPI, 0, 0, 0, 0, (1.0 / 2) * RPI, 0, 0, 0, 0, -(1.0 / 2) * RPI};
-// fixed transforms (3x4): auxT01, auxT09 (0.7071 literal, Robot.cpp:92-103), sole offset (:106-117)
-__constant__ double c_aux[3][12] = {{0, -1, 0, 0, 0.7071, 0, 0.7071, 0, -0.7071, 0, 0.7071, 0},
-                                    {1, 0, 0, 0, 0, 0.7071, 0.7071, 0, 0, -0.7071, 0.7071, 0},
-                                    {1, 0, 0, -0.0452, 0, 1, 0, 0, 0, 0, 1, 0}};
 // Rf_q0_, Robot.cpp:28-31
 __constant__ double c_rdes[9] = {0, 0, 1, 0, -1, 0, 1, 0, 0};
 
@@ -106,8 +99,9 @@ enum {
     P_GI6 = 2100,     // (G_f G_f')^-1 (6x6)
     P_GPI = 2136,     // G_f' (G_f G_f')^-1 (16x6): min-norm coefficients of a foot wrench
     P_TAU = 2232, P_QDD = 2256,
-    P_TAB = 2286,     // DH r|d|cos a|sin a (4x25), theta offsets (24), fixed transforms (36)
-    P_POLY = 2446,    // foot polynomials: rF[3][8] | lF[3][8] | counts (6, stored as doubles)
+    P_TAB = 2286,     // theta offsets (24)
+    P_POLY = 2310,    // foot polynomials: rF[3][8] | lF[3][8] | counts (6, stored as doubles)
+    P_MPCK = 2366,    // MPC record K | Px0 | Px1 (3 (N+1) doubles) when N <= MPC_LDS_MAXN
     P_END = 2504,
     // ---- scratch, phase A1 (kinematics + Newton-Euler)
     S0 = P_END,
@@ -148,6 +142,7 @@ __device__ __forceinline__ int lane_opaque()
     return l;
 }
 #define LANE lane_opaque()
+#define MPC_LDS_MAXN 45            // 3 (N+1) <= 138 doubles of LDS
 // diagnostic sub-phase stamps (s_memtime), compiled in only with -DLMH_SUBSTAMPS (LMH_DIAG=1 build): the
 // shipped kernels execute no stamp.  Only the debug kernel points g_dbg at its dump buffer.
 #ifdef LMH_SUBSTAMPS
@@ -180,13 +175,6 @@ __device__ __forceinline__ double x_force(const double *E, const double *Bm, con
     const double t2 = Bm[a] * f[3] + Bm[3 + a] * f[4] + Bm[6 + a] * f[5];
     return up ? t1 + t2 : t1;
 }
-// dense X[r][c]
-__device__ __forceinline__ double x_dense(const double *E, const double *Bm, int r, int c)
-{
-    if (r < 3) return (c < 3) ? E[c * 3 + r] : 0.0;
-    return (c < 3) ? Bm[(r - 3) * 3 + c] : E[(c - 3) * 3 + (r - 3)];
-}
-
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -285,7 +273,7 @@ __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
     const int lane = LANE;
     if (lane < 28) {
         double s, c;
-        if (lane < 24) sincos(L[P_Q + 6 + lane] + L[P_TAB + 100 + lane], &s, &c);
+        if (lane < 24) sincos(L[P_Q + 6 + lane] + L[P_TAB + lane], &s, &c);
         else if (lane == 24) { s = -1.0; c = CPI2; }              // theta[24] = -pi/2 (Robot.cpp:87)
         else sincos(L[P_Q + 3 + (lane - 25)], &s, &c);            // roll, pitch, yaw
         L[P_SC + 2 * lane] = s;
@@ -695,7 +683,6 @@ __device__ __forceinline__ double ldz(const double *L, bool cond, int idx_if, in
     const double v = L[cond ? idx_if : idx_safe];
     return cond ? v : 0.0;
 }
-#define IMIN(a, b) (((a) < (b)) ? (a) : (b))
 
 // J[row][col] of the dense 12 x 30 feet Jacobian from the compact store
 __device__ __forceinline__ double jdense(const double *L, int row, int col)
@@ -779,7 +766,9 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         for (int i = lane; i <= N; i += 64) {
             int kk = k + i;
             kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
-            const double K = mp[i], px0 = mp[(N + 1) + i], px1 = mp[2 * (N + 1) + i];
+            double K, px0, px1;
+            if (N <= MPC_LDS_MAXN) { K = L[P_MPCK + i]; px0 = L[P_MPCK + (N + 1) + i]; px1 = L[P_MPCK + 2 * (N + 1) + i]; }   // on-chip copy
+            else { K = mp[i]; px0 = mp[(N + 1) + i]; px1 = mp[2 * (N + 1) + i]; }
             sx += K * ((px0 * cxp + px1 * vxp) - P.zmpx[kk] * xs);
             sy += K * ((px0 * cyp + px1 * vyp) - P.zmpy[kk]);
         }
@@ -1355,12 +1344,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
 
 __device__ __forceinline__ void load_tables(double *L)
 {
-    for (int e = LANE; e < 160; e += 64) {
-        double v;
-        if (e < 25) v = c_dh_r[e]; else if (e < 50) v = c_dh_d[e - 25]; else if (e < 75) v = c_dh_ca[e - 50];
-        else if (e < 100) v = c_dh_sa[e - 75]; else if (e < 124) v = c_dh_off[e - 100]; else v = c_aux[(e - 124) / 12][(e - 124) % 12];
-        L[P_TAB + e] = v;
-    }
+    if (LANE < 24) L[P_TAB + LANE] = c_dh_off[LANE];               // theta offsets, Robot.cpp:59-87
 }
 __device__ __forceinline__ void load_common(double *L, const LmhDevParams &P, int inst)
 {
@@ -1385,6 +1369,10 @@ __device__ __forceinline__ void load_common(double *L, const LmhDevParams &P, in
         L[P_POLY + LANE] = (double)n;
     }
     load_tables(L);
+    if (P.horizon <= MPC_LDS_MAXN) {                               // gain row + Px columns stay on chip for the launch
+        const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
+        for (int e = LANE; e < 3 * (P.horizon + 1); e += 64) L[P_MPCK + e] = mp[e];
+    }
     WSYNC();
 }
 
