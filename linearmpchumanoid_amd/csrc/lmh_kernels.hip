@@ -516,18 +516,34 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
 }
 
 // Dynamics::computeM (CRBA, Dynamics.cpp:62-101) -> Mtop = [Ic0 | F2], Hl (per-limb joint blocks)
-// Lane map for the composite-inertia recursion: 12 lanes per chain = (row r, 3-column block cb), each
-// lane produces three entries; all five chains advance one level per pass.
-__device__ __forceinline__ void crba_y(double *L, int i, int slot, int r, int cb)      // Y = Ic_i X_i  (rows r, cols 3cb..3cb+2)
+// Lane map for the composite-inertia recursion: 12 lanes per chain = (row r, 3-column block cb); the
+// running composite inertia of a chain lives in the registers of its 12 lanes (three entries each), so the
+// recursion never round-trips it through LDS; all five chains advance one level per pass.
+
+// rows of the 6x6 body inertia [Ibar, [h]x; -[h]x, m 1] (Dynamics.cpp:4-13): entries (r, 3cb..3cb+2)
+__device__ __forceinline__ void body_row3(const double *mo, int r, int cb, double out[3])
 {
-    const double *I = L + A_IC + 36 * i + 6 * r, *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
-    const double l0 = cb ? 0.0 : I[0], l1 = cb ? 0.0 : I[1], l2 = cb ? 0.0 : I[2];
-    const double h0 = I[3], h1 = I[4], h2 = I[5];
+    const bool up = r < 3;
+    const int a = up ? r : r - 3;
+    const double hx = mo[9], hy = mo[10], hz = mo[11], m = mo[12];
+    const double c0 = (a == 0) ? 0.0 : (a == 1) ? hz : -hy;       // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]
+    const double c1 = (a == 0) ? -hz : (a == 1) ? 0.0 : hx;
+    const double c2 = (a == 0) ? hy : (a == 1) ? -hx : 0.0;
+    const double i0 = mo[3 * a], i1 = mo[3 * a + 1], i2 = mo[3 * a + 2];
+    const bool diag = (up == (cb == 0));                           // (up, cb=0): Ibar row; (down, cb=1): m e_a
+    out[0] = diag ? (up ? i0 : ((a == 0) ? m : 0.0)) : (up ? c0 : -c0);
+    out[1] = diag ? (up ? i1 : ((a == 1) ? m : 0.0)) : (up ? c1 : -c1);
+    out[2] = diag ? (up ? i2 : ((a == 2) ? m : 0.0)) : (up ? c2 : -c2);
+}
+// Y = Ic X_i for row r, columns 3cb..3cb+2, from the register-held row (lo = Ic[r][0:3], hi = Ic[r][3:6])
+__device__ __forceinline__ void crba_y_reg(double *L, int i, int slot, int r, int cb, const double lo[3], const double hi[3])
+{
+    const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
+    const double l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        // X[k][c] (k<3) = E[c][k];  X[3+k][c] = B[k][c];  X[3+k][3+c] = E[c][k]
         const double x0 = cb ? E[3 * c] : Bm[c], x1 = cb ? E[3 * c + 1] : Bm[3 + c], x2 = cb ? E[3 * c + 2] : Bm[6 + c];
-        L[A_YT + 36 * slot + 6 * r + 3 * cb + c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + h0 * x0 + h1 * x1 + h2 * x2;
+        L[A_YT + 36 * slot + 6 * r + 3 * cb + c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + hi[0] * x0 + hi[1] * x1 + hi[2] * x2;
     }
 }
 __device__ __forceinline__ void crba_z(const double *L, int i, int slot, int r, int cb, double out[3])   // (X_i' Y)(r, 3cb..)
@@ -535,7 +551,6 @@ __device__ __forceinline__ void crba_z(const double *L, int i, int slot, int r, 
     const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i, *Y = L + A_YT + 36 * slot + 3 * cb;
     const bool up = r < 3;
     const int a = up ? r : r - 3;
-    // X[k][r] (k<3) = E[r][k] (r<3) or 0;  X[3+k][r] = B[k][r] (r<3) or E[a][k]
     const double lo0 = up ? E[3 * a] : 0.0, lo1 = up ? E[3 * a + 1] : 0.0, lo2 = up ? E[3 * a + 2] : 0.0;
     const double hi0 = up ? Bm[a] : E[3 * a], hi1 = up ? Bm[3 + a] : E[3 * a + 1], hi2 = up ? Bm[6 + a] : E[3 * a + 2];
 #pragma unroll
@@ -546,53 +561,48 @@ __device__ __forceinline__ void crba_z(const double *L, int i, int slot, int r, 
 __device__ __forceinline__ void phase_crba(double *L)
 {
     const int lane = LANE;
-    // composite inertias start as the body inertias: [Ibar, [h]x; -[h]x, m 1]   (Dynamics.cpp:4-13)
-    for (int e = lane; e < 150; e += 64) {
-        const int i = f_body(e / 6), r = e % 6;
-        const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
-        double *o = L + A_IC + 36 * i + 6 * r;
-        const bool up = r < 3;
-        const int a = up ? r : r - 3;
-        const double hx = mo[9], hy = mo[10], hz = mo[11], m = mo[12];
-        // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]
-        const double c0 = (a == 0) ? 0.0 : (a == 1) ? hz : -hy;
-        const double c1 = (a == 0) ? -hz : (a == 1) ? 0.0 : hx;
-        const double c2 = (a == 0) ? hy : (a == 1) ? -hx : 0.0;
-        if (up) { o[0] = mo[3 * a]; o[1] = mo[3 * a + 1]; o[2] = mo[3 * a + 2]; o[3] = c0; o[4] = c1; o[5] = c2; }
-        else { o[0] = -c0; o[1] = -c1; o[2] = -c2; o[3] = (a == 0) ? m : 0.0; o[4] = (a == 1) ? m : 0.0; o[5] = (a == 2) ? m : 0.0; }
-    }
     SUBSTAMP(9);
     const int ch = lane / 12, t = lane % 12, r = t >> 1, cb = t & 1;
-    for (int dl = 6; dl >= 2; dl--) {                              // chain depth of the frames folded into their parents
-        const int nf = (dl == 6) ? 2 : (dl >= 3) ? 4 : 5;
-        const bool on = lane < 12 * nf;
-        const int i = f_chain_base(ch) + dl - 1;
-        WSYNC();
-        if (on) crba_y(L, i, ch, r, cb);
+    const int nact = (ch < 2) ? 6 : (ch < 4) ? 5 : 2;             // actuated frames of this lane's chain
+    const int cbase = f_chain_base(ch < 5 ? ch : 4);
+    double ic[3] = {0.0, 0.0, 0.0};                               // Ic_i[r][3cb .. 3cb+2] of the frame being folded
+    for (int dl = 6; dl >= 1; dl--) {                              // chain depth of the frames folded into their parents
+        const bool on = (lane < 60) && (dl <= nact);
+        const int i = cbase + dl - 1;
+        if (on && dl == nact) body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, r, cb, ic);   // leaf: Ic = I (Dynamics.cpp:72)
+        if (on && cb == 0) L[A_FB + 6 * (f_act(i) - 1) + r] = ic[2];                    // f = Ic_i S for the joint columns
+        const double p0 = __shfl_xor(ic[0], 1, 64), p1 = __shfl_xor(ic[1], 1, 64), p2 = __shfl_xor(ic[2], 1, 64);
+        const double lo[3] = {cb ? p0 : ic[0], cb ? p1 : ic[1], cb ? p2 : ic[2]};
+        const double hi[3] = {cb ? ic[0] : p0, cb ? ic[1] : p1, cb ? ic[2] : p2};
+        WSYNC();                                                   // A_YT of the previous level has been consumed
+        if (on) crba_y_reg(L, i, ch, r, cb, lo, hi);
         WSYNC();
         if (on) {
             double z[3];
             crba_z(L, i, ch, r, cb, z);
-            double *o = L + A_IC + 36 * (i - 1) + 6 * r + 3 * cb;  // parent of a depth >= 2 frame is i-1
-            o[0] += z[0]; o[1] += z[1]; o[2] += z[2];
+            if (dl >= 2) {                                         // Ic[parent] = Ic[parent] + X' Ic X (Dynamics.cpp:82), parent = i-1
+                double bp3[3];
+                body_row3(L + P_MODEL + LMH_BODY_STRIDE * (i - 1), r, cb, bp3);
+                ic[0] = bp3[0] + z[0]; ic[1] = bp3[1] + z[1]; ic[2] = bp3[2] + z[2];
+            } else {                                               // depth 1: park the contribution to the base
+                const int slot = (ch == 4) ? 0 : 4 - ch;           // reference order head, LA, RA, LL, RL
+                double *o = L + A_XN + 36 * slot + 6 * r + 3 * cb;
+                o[0] = z[0]; o[1] = z[1]; o[2] = z[2];
+            }
         }
     }
     WSYNC();
     SUBSTAMP(10);
-    if (lane < 60) crba_y(L, f_root(ch), ch, r, cb);               // depth-1 frames, slots in the reference's order
-    WSYNC();
-    if (lane < 60) {
-        double z[3];
-        crba_z(L, f_root(ch), ch, r, cb, z);
-        double *o = L + A_FB + 36 * ch + 6 * r + 3 * cb;           // park the five contributions
-        o[0] = z[0]; o[1] = z[1]; o[2] = z[2];
-    }
-    WSYNC();
-    if (lane < 36) {                                               // Ic0 += head, LA, RA, LL, RL (Dynamics.cpp:80-82 order)
-        double acc = L[A_IC + lane];
+    if (lane < 12) {                                               // Ic0 = I0 + head + LA + RA + LL + RL (Dynamics.cpp:80-82 order)
+        double acc[3];
+        body_row3(L + P_MODEL, r, cb, acc);
 #pragma unroll
-        for (int sl = 0; sl < 5; sl++) acc += L[A_FB + 36 * sl + lane];
-        L[P_MTOP + 30 * (lane / 6) + lane % 6] = acc;
+        for (int sl = 0; sl < 5; sl++) {
+            const double *o = L + A_XN + 36 * sl + 6 * r + 3 * cb;
+            acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
+        }
+        double *mt = L + P_MTOP + 30 * r + 3 * cb;
+        mt[0] = acc[0]; mt[1] = acc[1]; mt[2] = acc[2];
     }
     WSYNC();
     SUBSTAMP(11);
@@ -600,11 +610,6 @@ __device__ __forceinline__ void phase_crba(double *L)
     for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
     const int ja = lane >> 1, hf = lane & 1;
     const int jf = f_jframe(ja), jst = f_jstart(ja), jd = ja - jst + 1;
-    if (lane < 48) {
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) L[A_FB + 6 * ja + 3 * hf + kk] = L[A_IC + 36 * jf + 6 * (3 * hf + kk) + 2];
-    }
-    WSYNC();
     if (lane < 48 && hf == 0) L[P_HL + 6 * ja + (ja - jst)] = L[A_FB + 6 * ja + 2];
     int cur = 0;
     for (int sdep = 1; sdep <= 6; sdep++) {
