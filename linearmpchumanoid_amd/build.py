@@ -21,7 +21,10 @@ def build(force=False, verbose=False):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     diag = ["-DLMH_SUBSTAMPS"] if os.environ.get("LMH_DIAG") == "1" else []      # in-kernel sub-phase stamps (diagnostic build)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *diag,
+    # iterative-ilp machine scheduler: the kernels run one wave per SIMD, so latency (not register pressure /
+    # occupancy) is what the scheduler should optimise; measured +19 % ticks/s over the default strategy.
+    sched = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *sched, *diag,
            *[os.path.join(CSRC, f) for f in SOURCES], "-o", SO]
     if verbose:
         print(" ".join(cmd))
