@@ -410,42 +410,37 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
         L[A_ACCG + lane] = x_mot(L + A_XE, L + A_XB, g, lane);
         L[A_ACC0 + lane] = 0.0;
     }
-    {   // velocity sweep, lanes (chain, k)
-        const int c = lane / 6, k = lane % 6;
-        for (int d = 0; d < 6; d++) {
+    {   // velocity and acceleration sweeps, software-pipelined by one level: step d computes vel at chain depth d
+        // and acc (with / without gravity) at depth d-1.  Lanes (chain, which, k); straight-line code with guarded
+        // stores (operand addresses are always inside the LDS arrays) so that each step is one basic block.
+        const int c = (lane < 60) ? lane / 12 : 4, which = (lane % 12) / 6, k = lane % 6;
+        const int base = f_chain_base(c);
+        const int nact = (c < 2) ? 6 : (c < 4) ? 5 : 2;           // actuated frames on the chain
+        const int nacc = (c < 2) ? 7 : nact;                      // legs: the sole frame needs its acceleration too
+        const int adj = (c == 0) ? 0 : (c == 1) ? 1 : 2;          // act(frame) = frame - adj on this chain (Robot.cpp:172)
+        const int abase = which ? A_ACC0 : A_ACCG;
+        const bool live = lane < 60;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
             WSYNC();
-            if (lane < 30) {
-                const int i = f_chain(c, d);
-                if (i >= 0 && f_act(i) != 0) {
-                    const double *vp = L + A_VEL + 6 * f_parent(i);
-                    double val = x_mot(L + A_XE + 9 * i, L + A_XB + 9 * i, vp, k);
-                    if (k == 2) val += L[P_VHS + 5 + f_act(i)];
-                    L[A_VEL + 6 * i + k] = val;
-                }
-            }
-        }
-    }
-    SUBSTAMP(5);
-    {   // acceleration sweeps (with / without gravity), lanes (chain, which, k); includes the soles
-        const int c = lane / 12, which = (lane % 12) / 6, k = lane % 6;
-        const int base = which ? A_ACC0 : A_ACCG;
-        for (int d = 0; d < 7; d++) {
-            WSYNC();
-            if (lane < 60) {
-                const int i = f_chain(c, d);
-                if (i >= 0 && !(c == 4 && d == 2)) {
-                    const double *ap = L + base + 6 * f_parent(i);
-                    double val = x_mot(L + A_XE + 9 * i, L + A_XB + 9 * i, ap, k);
-                    if (f_act(i) != 0) {
-                        const double *vi = L + A_VEL + 6 * i;
-                        const double qd = L[P_VHS + 5 + f_act(i)];
-                        // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
-                        const double cs = (k == 0) ? vi[1] : (k == 1) ? -vi[0] : (k == 3) ? vi[4] : (k == 4) ? -vi[3] : 0.0;
-                        val += cs * qd;
-                    }
-                    L[base + 6 * i + k] = val;
-                }
-            }
+            // ---- velocity, depth index d
+            const int iv = base + ((d < nact) ? d : 0);
+            const int pv = (d == 0) ? 0 : iv - 1;
+            double vval = x_mot(L + A_XE + 9 * iv, L + A_XB + 9 * iv, L + A_VEL + 6 * pv, k);
+            const double qdv = L[P_VHS + 5 + iv - adj];
+            vval += (k == 2) ? qdv : 0.0;
+            // ---- acceleration, depth index d-1
+            const int e = d - 1;
+            const int ia = base + ((e >= 0 && e < nacc) ? e : 0);
+            const int pa = (e <= 0) ? 0 : ia - 1;
+            double aval = x_mot(L + A_XE + 9 * ia, L + A_XB + 9 * ia, L + abase + 6 * pa, k);
+            const double *vi = L + A_VEL + 6 * ia;
+            const double qda = L[P_VHS + 5 + ia - adj];
+            // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
+            const double cs = (k == 0) ? vi[1] : (k == 1) ? -vi[0] : (k == 3) ? vi[4] : (k == 4) ? -vi[3] : 0.0;
+            aval += (e < nact) ? cs * qda : 0.0;
+            if (live && which == 0 && d < nact) L[A_VEL + 6 * iv + k] = vval;
+            if (live && e >= 0 && e < nacc) L[abase + 6 * ia + k] = aval;
         }
     }
     WSYNC();
