@@ -313,20 +313,18 @@ __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
         L[A_T + lane] = val;
     }
     SUBSTAMP(1);
-    const int c = lane / 12, el = lane % 12, r = el >> 2, col = el & 3;
+    const int c = (lane < 60) ? lane / 12 : 4, el = lane % 12, r = el >> 2, col = el & 3;
+#pragma unroll
     for (int s = 0; s < 8; s++) {
         WSYNC();
-        if (lane < 60) {
-            int dst, src, loc;
-            fk_sched(c, s, &dst, &src, &loc);
-            if (dst >= 0) {
-                const double *Ts = L + A_T + 12 * src + 4 * r;
-                const double *Lo = L + A_LC + 12 * loc + col;
-                double val = Ts[0] * Lo[0] + Ts[1] * Lo[4] + Ts[2] * Lo[8];
-                if (col == 3) val += Ts[3];
-                L[A_T + 12 * dst + el] = val;
-            }
-        }
+        int dst, src, loc;
+        fk_sched(c, s, &dst, &src, &loc);
+        const bool on = (lane < 60) && (dst >= 0);
+        const double *Ts = L + A_T + 12 * (on ? src : 0) + 4 * r;
+        const double *Lo = L + A_LC + 12 * (on ? loc : 0) + col;
+        double val = Ts[0] * Lo[0] + Ts[1] * Lo[4] + Ts[2] * Lo[8];
+        val += (col == 3) ? Ts[3] : 0.0;
+        if (on) L[A_T + 12 * dst + el] = val;
     }
     WSYNC();
 }
@@ -446,8 +444,9 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
     WSYNC();
     SUBSTAMP(6);
     // body forces f = I a + v x* (I v), one lane per (body, which)
-    if (lane < 50) {
-        const int which = lane / 25, i = f_body(lane % 25);
+    {
+        const bool fon = lane < 50;
+        const int which = fon ? lane / 25 : 0, i = f_body(lane % 25);
         const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
         const double *v = L + A_VEL + 6 * i, *a = L + (which ? A_ACC0 : A_ACCG) + 6 * i;
         const double m = mo[12], hx = mo[9], hy = mo[10], hz = mo[11];
@@ -473,31 +472,35 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
         f1 += (v[2] * l0 - v[0] * l2);
         f2 += (v[0] * l1 - v[1] * l0);
         double *fo = L + (which ? A_F0 : A_FG) + 6 * i;
-        fo[0] = n0; fo[1] = n1; fo[2] = n2; fo[3] = f0; fo[4] = f1; fo[5] = f2;
+        if (fon) { fo[0] = n0; fo[1] = n1; fo[2] = n2; fo[3] = f0; fo[4] = f1; fo[5] = f2; }
     }
     SUBSTAMP(7);
-    {   // backward sweep, lanes (chain, which, k): depth 6 -> 2 accumulate into the parent
-        const int c = lane / 12, which = (lane % 12) / 6, k = lane % 6;
-        const int base = which ? A_F0 : A_FG;
+    {   // backward sweep, lanes (chain, which, k): depth 6 -> 2 accumulate into the parent (straight-line, guarded stores)
+        const int c = (lane < 60) ? lane / 12 : 4, which = (lane % 12) / 6, k = lane % 6;
+        const int fb = which ? A_F0 : A_FG;
+        const int cb0 = f_chain_base(c);
+        const int nact = (c < 2) ? 6 : (c < 4) ? 5 : 2;
+#pragma unroll
         for (int d = 5; d >= 1; d--) {
             WSYNC();
-            if (lane < 60) {
-                const int i = f_chain(c, d);
-                if (i >= 0 && f_act(i) != 0) {
-                    const int p = f_parent(i);
-                    L[base + 6 * p + k] += x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + base + 6 * i, k);
-                }
-            }
+            const bool on = (lane < 60) && (d < nact);
+            const int i = cb0 + (on ? d : 1);                      // parent of a depth >= 2 frame is i - 1
+            const double add = x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + fb + 6 * i, k);
+            const double old = L[fb + 6 * (i - 1) + k];
+            if (on) L[fb + 6 * (i - 1) + k] = old + add;
         }
         WSYNC();
         SUBSTAMP(8);
-        if (lane < 12) {                                           // base, reference order head, LA, RA, LL, RL
-            const int w2 = lane / 6, k2 = lane % 6, b2 = w2 ? A_F0 : A_FG;
-            double acc = L[b2 + k2];
-            for (int r = 0; r < 5; r++) {
-                const int i = f_root(r);
-                acc += x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + b2 + 6 * i, k2);
-            }
+        {   // the five chain roots project onto the base in parallel, then are summed in the reference's order
+            const double contrib = x_force(L + A_XE + 9 * cb0, L + A_XB + 9 * cb0, L + fb + 6 * cb0, k);
+            if (lane < 60) L[A_VEL + 12 * c + 6 * which + k] = contrib;       // A_VEL is dead after the body forces
+        }
+        WSYNC();
+        if (lane < 12) {                                           // base: head, LA, RA, LL, RL (Dynamics.cpp:157-162 order)
+            const int w2 = lane / 6, k2 = lane % 6;
+            double acc = L[(w2 ? A_F0 : A_FG) + k2];
+#pragma unroll
+            for (int cc = 4; cc >= 0; cc--) acc += L[A_VEL + 12 * cc + 6 * w2 + k2];
             if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc;
         }
         if (lane >= 16 && lane < 40) L[P_C + 6 + (lane - 16)] = L[A_FG + 6 * f_jframe(lane - 16) + 2];
