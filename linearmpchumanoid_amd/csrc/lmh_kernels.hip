@@ -533,17 +533,6 @@ __device__ __forceinline__ void body_row3(const double *mo, int r, int cb, doubl
     out[1] = diag ? (up ? i1 : ((a == 1) ? m : 0.0)) : (up ? c1 : -c1);
     out[2] = diag ? (up ? i2 : ((a == 2) ? m : 0.0)) : (up ? c2 : -c2);
 }
-// Y = Ic X_i for row r, columns 3cb..3cb+2, from the register-held row (lo = Ic[r][0:3], hi = Ic[r][3:6])
-__device__ __forceinline__ void crba_y_reg(double *L, int i, int slot, int r, int cb, const double lo[3], const double hi[3])
-{
-    const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
-    const double l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const double x0 = cb ? E[3 * c] : Bm[c], x1 = cb ? E[3 * c + 1] : Bm[3 + c], x2 = cb ? E[3 * c + 2] : Bm[6 + c];
-        L[A_YT + 36 * slot + 6 * r + 3 * cb + c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + hi[0] * x0 + hi[1] * x1 + hi[2] * x2;
-    }
-}
 __device__ __forceinline__ void crba_z(const double *L, int i, int slot, int r, int cb, double out[3])   // (X_i' Y)(r, 3cb..)
 {
     const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i, *Y = L + A_YT + 36 * slot + 3 * cb;
@@ -564,25 +553,37 @@ __device__ __forceinline__ void phase_crba(double *L)
     const int nact = (ch < 2) ? 6 : (ch < 4) ? 5 : 2;             // actuated frames of this lane's chain
     const int cbase = f_chain_base(ch < 5 ? ch : 4);
     double ic[3] = {0.0, 0.0, 0.0};                               // Ic_i[r][3cb .. 3cb+2] of the frame being folded
+#pragma unroll
     for (int dl = 6; dl >= 1; dl--) {                              // chain depth of the frames folded into their parents
         const bool on = (lane < 60) && (dl <= nact);
-        const int i = cbase + dl - 1;
-        if (on && dl == nact) body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, r, cb, ic);   // leaf: Ic = I (Dynamics.cpp:72)
-        if (on && cb == 0) L[A_FB + 6 * (f_act(i) - 1) + r] = ic[2];                    // f = Ic_i S for the joint columns
+        const int i = cbase + (on ? dl - 1 : 0);                   // safe frame index for the idle lanes
+        double leaf[3];
+        body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, r, cb, leaf);
+        if (dl == nact) { ic[0] = leaf[0]; ic[1] = leaf[1]; ic[2] = leaf[2]; }   // leaf: Ic = I (Dynamics.cpp:72)
+        if (on && cb == 0) L[A_FB + 6 * (f_act(i) - 1) + r] = ic[2];             // f = Ic_i S for the joint columns
         const double p0 = __shfl_xor(ic[0], 1, 64), p1 = __shfl_xor(ic[1], 1, 64), p2 = __shfl_xor(ic[2], 1, 64);
         const double lo[3] = {cb ? p0 : ic[0], cb ? p1 : ic[1], cb ? p2 : ic[2]};
         const double hi[3] = {cb ? ic[0] : p0, cb ? ic[1] : p1, cb ? ic[2] : p2};
         WSYNC();                                                   // A_YT of the previous level has been consumed
-        if (on) crba_y_reg(L, i, ch, r, cb, lo, hi);
+        {
+            const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
+            const double l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
+            double y[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double x0 = cb ? E[3 * c] : Bm[c], x1 = cb ? E[3 * c + 1] : Bm[3 + c], x2 = cb ? E[3 * c + 2] : Bm[6 + c];
+                y[c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + hi[0] * x0 + hi[1] * x1 + hi[2] * x2;
+            }
+            if (on) { double *yo = L + A_YT + 36 * ch + 6 * r + 3 * cb; yo[0] = y[0]; yo[1] = y[1]; yo[2] = y[2]; }
+        }
         WSYNC();
-        if (on) {
-            double z[3];
-            crba_z(L, i, ch, r, cb, z);
+        {
+            double z[3], bp3[3];
+            crba_z(L, i, (lane < 60) ? ch : 0, r, cb, z);
+            body_row3(L + P_MODEL + LMH_BODY_STRIDE * ((i > 0) ? i - 1 : 0), r, cb, bp3);
             if (dl >= 2) {                                         // Ic[parent] = Ic[parent] + X' Ic X (Dynamics.cpp:82), parent = i-1
-                double bp3[3];
-                body_row3(L + P_MODEL + LMH_BODY_STRIDE * (i - 1), r, cb, bp3);
-                ic[0] = bp3[0] + z[0]; ic[1] = bp3[1] + z[1]; ic[2] = bp3[2] + z[2];
-            } else {                                               // depth 1: park the contribution to the base
+                if (on) { ic[0] = bp3[0] + z[0]; ic[1] = bp3[1] + z[1]; ic[2] = bp3[2] + z[2]; }
+            } else if (on) {                                       // depth 1: park the contribution to the base
                 const int slot = (ch == 4) ? 0 : 4 - ch;           // reference order head, LA, RA, LL, RL
                 double *o = L + A_XN + 36 * slot + 6 * r + 3 * cb;
                 o[0] = z[0]; o[1] = z[1]; o[2] = z[2];
