@@ -607,34 +607,36 @@ __device__ __forceinline__ void phase_crba(double *L)
     SUBSTAMP(11);
     // joint columns: f = Ic_i S, walked up the chain (Dynamics.cpp:83-93); 2 lanes per joint (k<3 | k>=3)
     for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
-    const int ja = lane >> 1, hf = lane & 1;
+    const int ja = (lane < 48) ? lane >> 1 : 0, hf = lane & 1;
     const int jf = f_jframe(ja), jst = f_jstart(ja), jd = ja - jst + 1;
     if (lane < 48 && hf == 0) L[P_HL + 6 * ja + (ja - jst)] = L[A_FB + 6 * ja + 2];
-    int cur = 0;
-    for (int sdep = 1; sdep <= 6; sdep++) {
+#pragma unroll
+    for (int sdep = 1; sdep <= 6; sdep++) {                         // straight-line steps, guarded stores
         WSYNC();
-        if (lane < 48 && sdep <= jd) {
-            const int j = jf - (sdep - 1);                         // frame whose X' is applied
-            const double *E = L + A_XE + 9 * j, *Bm = L + A_XB + 9 * j, *f = L + A_FB + 144 * cur + 6 * ja;
-            const double *g = hf ? f + 3 : f;
-            double o3[3];
+        const int cur = (sdep - 1) & 1;
+        const bool on = (lane < 48) && (sdep <= jd);
+        const int j = on ? jf - (sdep - 1) : jf;                    // frame whose X' is applied
+        const double *E = L + A_XE + 9 * j, *Bm = L + A_XB + 9 * j, *f = L + A_FB + 144 * cur + 6 * ja;
+        const double *g = hf ? f + 3 : f;
+        double o3[3];
 #pragma unroll
-            for (int kk = 0; kk < 3; kk++) {
-                const double t1 = E[3 * kk] * g[0] + E[3 * kk + 1] * g[1] + E[3 * kk + 2] * g[2];
-                const double t2 = Bm[kk] * f[3] + Bm[3 + kk] * f[4] + Bm[6 + kk] * f[5];
-                o3[kk] = hf ? t1 : t1 + t2;
-                L[A_FB + 144 * (cur ^ 1) + 6 * ja + 3 * hf + kk] = o3[kk];
-            }
+        for (int kk = 0; kk < 3; kk++) {
+            const double t1 = E[3 * kk] * g[0] + E[3 * kk + 1] * g[1] + E[3 * kk + 2] * g[2];
+            const double t2 = Bm[kk] * f[3] + Bm[3 + kk] * f[4] + Bm[6 + kk] * f[5];
+            o3[kk] = hf ? t1 : t1 + t2;
+        }
+        if (on) {
+            double *fo = L + A_FB + 144 * (cur ^ 1) + 6 * ja + 3 * hf;
+            fo[0] = o3[0]; fo[1] = o3[1]; fo[2] = o3[2];
             if (sdep == jd) {
-#pragma unroll
-                for (int kk = 0; kk < 3; kk++) L[P_MTOP + 30 * (3 * hf + kk) + 6 + ja] = o3[kk];    // F2 column
+                double *mt = L + P_MTOP + 30 * (3 * hf) + 6 + ja;   // F2 column
+                mt[0] = o3[0]; mt[30] = o3[1]; mt[60] = o3[2];
             } else if (hf == 0) {
-                const int aj = ja - sdep;                          // joint of parent(j)
+                const int aj = ja - sdep;                           // joint of parent(j)
                 L[P_HL + 6 * aj + (ja - jst)] = o3[2];
                 L[P_HL + 6 * ja + (aj - jst)] = o3[2];
             }
         }
-        cur ^= 1;
     }
     WSYNC();
 }
