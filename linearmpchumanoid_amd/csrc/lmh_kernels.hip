@@ -27,6 +27,7 @@
 // The minimiser is unique (H is SPD), so this equals what qpOASES returns in the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "lmh_device.h"
 #include "../../include/lmh.h"
 
@@ -260,8 +261,12 @@ __device__ __forceinline__ v4d mfma_tile(FA a_of, FB b_of)
     const int r = LANE & 15, kq = LANE >> 4;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_of(r, 4 * kk + kq), b_of(4 * kk + kq, r), acc, 0, 0, 0);
+    for (int kk = 0; kk < KSTEPS; kk++) {
+        double bv;
+        if constexpr (std::is_invocable_v<FB, int, int, int, int>) bv = b_of(4 * kk + kq, r, kk, kq);   // k split into its compile-time / lane parts
+        else bv = b_of(4 * kk + kq, r);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_of(r, 4 * kk + kq), bv, acc, 0, 0, 0);
+    }
     return acc;
 }
 
@@ -271,6 +276,14 @@ __device__ __forceinline__ v4d mfma_tile(FA a_of, FB b_of)
 __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
 {
     const int lane = LANE;
+    // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos
+    double c0[6], c1[6], c2[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+        const int e = lane + 64 * u;
+        const double *cf = lcoef + 3 * ((e < 336) ? e : 0);
+        c0[u] = cf[0]; c1[u] = cf[1]; c2[u] = cf[2];
+    }
     if (lane < 28) {
         double s, c;
         if (lane < 24) sincos(L[P_Q + 6 + lane] + L[P_TAB + lane], &s, &c);
@@ -285,13 +298,6 @@ __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
     // c0 + c1 cos(theta) + c2 sin(theta) with model constants (c0, c1, c2) tabulated once on the host
     // (lcoef, L2-resident); the zero / one coefficients make the fused form bit-identical to the products.
     {
-        double c0[6], c1[6], c2[6];
-#pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const int e = lane + 64 * u;
-            const double *cf = lcoef + 3 * ((e < 336) ? e : 0);
-            c0[u] = cf[0]; c1[u] = cf[1]; c2[u] = cf[2];
-        }
 #pragma unroll
         for (int u = 0; u < 6; u++) {
             const int e = lane + 64 * u;
@@ -704,7 +710,23 @@ __device__ __forceinline__ double jdense(const double *L, int row, int col)
 // Dynamics::centroidalMatrixAndBias (Dynamics.cpp:103-121), Robot::computeComMomentum
 // (Robot.cpp:300-310), Mpc3dLip::compute (mpcLinearPendulum.cpp:78-109), PD references
 // (controller.cpp:296-386).
-__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, int *k_out, int *phase_out)
+// Reference samples of one evaluation, fetched from HBM/L2 at the top of controller_eval so that their latency
+// hides behind the kinematics: lane i holds zmp[k + i] (first 64 samples of the preview window).
+struct RefPrefetch { int k; double zx, zy, xs; int ph; };
+__device__ __forceinline__ RefPrefetch prefetch_refs(const LmhDevParams &P, int inst, double t)
+{
+    RefPrefetch r;
+    r.k = (int)(t / P.dt);                                         // mpcLinearPendulum.cpp:92 (fp64, same op order)
+    int kk = r.k + LANE;
+    kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
+    r.zx = P.zmpx[kk]; r.zy = P.zmpy[kk];
+    r.xs = P.xscale ? P.xscale[inst] : 1.0;                        // walking extension: per-instance step length
+    r.ph = 0;
+    if (P.phase) { const int k0 = (r.k < 0) ? 0 : (r.k >= P.n_samples ? P.n_samples - 1 : r.k); r.ph = P.phase[k0]; }
+    return r;
+}
+
+__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre, int *k_out, int *phase_out)
 {
     const int lane = LANE;
     int flags = 0;
@@ -761,22 +783,26 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
     SUBSTAMP(13);
     // ---- MPC: u0 = -K (Px x_k - z[k : k+N+1])
     const int N = P.horizon;
-    const int k = (int)(t / P.dt);                                 // mpcLinearPendulum.cpp:92 (fp64, same op order)
+    const int k = pre.k;
     if (k < 0 || k + N >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;
     const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
     const double zcom = mp[3 * (N + 1)];
     {
         const double cxp = L[P_COM], cyp = L[P_COM + 1], vxp = L[P_COMV], vyp = L[P_COMV + 1];
-        const double xs = P.xscale ? P.xscale[inst] : 1.0;       // walking extension: per-instance step length
+        const double xs = pre.xs;
         double sx = 0.0, sy = 0.0;
         for (int i = lane; i <= N; i += 64) {
-            int kk = k + i;
-            kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
+            double zxv = pre.zx, zyv = pre.zy;
+            if (i >= 64) {                                         // only N = 64 reaches a second round
+                int kk = k + i;
+                kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
+                zxv = P.zmpx[kk]; zyv = P.zmpy[kk];
+            }
             double K, px0, px1;
             if (N <= MPC_LDS_MAXN) { K = L[P_MPCK + i]; px0 = L[P_MPCK + (N + 1) + i]; px1 = L[P_MPCK + 2 * (N + 1) + i]; }   // on-chip copy
             else { K = mp[i]; px0 = mp[(N + 1) + i]; px1 = mp[2 * (N + 1) + i]; }
-            sx += K * ((px0 * cxp + px1 * vxp) - P.zmpx[kk] * xs);
-            sy += K * ((px0 * cyp + px1 * vyp) - P.zmpy[kk]);
+            sx += K * ((px0 * cxp + px1 * vxp) - zxv * xs);
+            sy += K * ((px0 * cyp + px1 * vyp) - zyv);
         }
         sx = wave_sum(sx); sy = wave_sum(sy);
         const double ux = -sx, uy = -sy;
@@ -790,8 +816,7 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
             L[P_MPC + 7] = uy;
         }
     }
-    int ph = 0;
-    if (P.phase) { int kk = (k < 0) ? 0 : (k >= P.n_samples ? P.n_samples - 1 : k); ph = P.phase[kk]; }
+    const int ph = pre.ph;
     *k_out = k; *phase_out = ph;
     WSYNC();
     SUBSTAMP(14);
@@ -1063,9 +1088,14 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     // ---- Cm = Om^-1 + U D^-1 U'  and  V = U bp'  on the matrix cores (K = 30 padded to 32)
     const int ld = 19;
     {
-        auto a_u = [&](int m, int k) { return ldz(L, m < nU && k < 30, B_U + 30 * m + k, B_U); };
-        auto b_ud = [&](int k, int n) { return ldz(L, n < nU && k < 30, B_U + 30 * n + k, B_U) * ((k < 3) ? idp : (k < 6) ? ida : idj); };
-        auto b_bp = [&](int k, int n) { return ldz(L, n < 7 && k < 30, B_BP + 7 * k + n, B_BP); };
+        auto a_u = [=](int m, int k) { return ldz(L, m < nU && k < 30, B_U + 30 * m + k, B_U); };
+        // D^-1 entry of column k = 4 kk + kq: one two-way select per (compile-time) kk -- a three-way select of the
+        // captured scalars is lowered to a scratch-resident table lookup
+        auto b_ud = [=](int k, int n, int kk, int kq) {
+            const double sc = (kk == 0) ? ((kq < 3) ? idp : ida) : (kk == 1) ? ((kq < 2) ? ida : idj) : idj;
+            return ldz(L, n < nU && k < 30, B_U + 30 * n + k, B_U) * sc;
+        };
+        auto b_bp = [=](int k, int n) { return ldz(L, n < 7 && k < 30, B_BP + 7 * k + n, B_BP); };
         const v4d cm = mfma_tile<8>(a_u, b_ud);
         const v4d vv = mfma_tile<8>(a_u, b_bp);
         if constexpr (NU > 16) {                                             // rows/cols 16, 17 (angular-momentum weight set): plain loops
@@ -1122,10 +1152,10 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
     // ---- Y = bp' - D^-1 U' t'   (30 x 7; two row tiles, K = nU padded to 20)
     {
-        auto b_t = [&](int k, int n) { return ldz(L, k < nU && n < 7, B_K + ld * (nU + n) + k, B_K); };
+        auto b_t = [=](int k, int n) { return ldz(L, k < nU && n < 7, B_K + ld * (nU + n) + k, B_K); };
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
-            auto a_ut = [&](int m, int k) { const int i = 16 * mt + m; return ldz(L, i < 30 && k < nU, B_U + 30 * k + i, B_U); };
+            auto a_ut = [=](int m, int k) { const int i = 16 * mt + m; return ldz(L, i < 30 && k < nU, B_U + 30 * k + i, B_U); };
             const v4d yy = mfma_tile<5>(a_ut, b_t);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -1138,8 +1168,8 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     if (dbgp && LANE == 0) dbgp[4010] = (double)clock64();
     // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g  (one tile, K = 30 padded to 32); Si = S^-1
     {
-        auto a_m = [&](int m, int k) { return ldz(L, m < 6 && k < 30, P_MTOP + 30 * m + k, P_MTOP); };
-        auto b_y = [&](int k, int n) { return ldz(L, n < 7 && k < 30, P_Y + 7 * k + n, P_Y); };
+        auto a_m = [=](int m, int k) { return ldz(L, m < 6 && k < 30, P_MTOP + 30 * m + k, P_MTOP); };
+        auto b_y = [=](int k, int n) { return ldz(L, n < 7 && k < 30, P_Y + 7 * k + n, P_Y); };
         const v4d sy = mfma_tile<8>(a_m, b_y);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -1162,16 +1192,16 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     WSYNC();
     // ---- T1 = Jb Si (12x6);  [W | h] = [w_force I + T1 Jb' | T1 d]   (K = 6 padded to 8)
     {
-        auto a_jb = [&](int m, int k) { const bool ok = m < 12 && k < 6; const double v = jdense(L, ok ? m : 0, ok ? k : 0); return ok ? v : 0.0; };
-        auto b_si = [&](int k, int n) { return ldz(L, k < 6 && n < 6, P_SI + 6 * k + n, P_SI); };
+        auto a_jb = [=](int m, int k) { const bool ok = m < 12 && k < 6; const double v = jdense(L, ok ? m : 0, ok ? k : 0); return ok ? v : 0.0; };
+        auto b_si = [=](int k, int n) { return ldz(L, k < 6 && n < 6, P_SI + 6 * k + n, P_SI); };
         const v4d t1 = mfma_tile<2>(a_jb, b_si);
 #pragma unroll
         for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12 && tr < 6) L[B_T1 + 6 * row + tr] = t1[g]; }
     }
     WSYNC();
     {
-        auto a_t1 = [&](int m, int k) { return ldz(L, m < 12 && k < 6, B_T1 + 6 * m + k, B_T1); };
-        auto b_jd = [&](int k, int n) { const bool kin = k < 6; const double vj = jdense(L, (n < 12) ? n : 0, kin ? k : 0); const double vd = L[P_D6 + (kin ? k : 0)]; return !kin ? 0.0 : (n < 12) ? vj : (n == 12) ? vd : 0.0; };
+        auto a_t1 = [=](int m, int k) { return ldz(L, m < 12 && k < 6, B_T1 + 6 * m + k, B_T1); };
+        auto b_jd = [=](int k, int n) { const bool kin = k < 6; const double vj = jdense(L, (n < 12) ? n : 0, kin ? k : 0); const double vd = L[P_D6 + (kin ? k : 0)]; return !kin ? 0.0 : (n < 12) ? vj : (n == 12) ? vd : 0.0; };
         const v4d ww = mfma_tile<2>(a_t1, b_jd);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -1185,10 +1215,10 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     // ---- cone QP data: WG = W G (12 x 32), Pm = G' WG + eps I (32 x 32), qv = G' h ; G[k][j] is the
     //      generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
     {
-        auto a_w = [&](int m, int k) { return ldz(L, m < 12 && k < 12, P_W + 12 * m + k, P_W); };
+        auto a_w = [=](int m, int k) { return ldz(L, m < 12 && k < 12, P_W + 12 * m + k, P_W); };
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            auto b_g = [&](int k, int n) { const int kk = k - 6 * nt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * n + kk, P_GCOL); };
+            auto b_g = [=](int k, int n) { const int kk = k - 6 * nt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * n + kk, P_GCOL); };
             const v4d wg = mfma_tile<3>(a_w, b_g);
 #pragma unroll
             for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12) L[C_WG + 32 * row + 16 * nt + tr] = wg[g]; }
@@ -1203,10 +1233,10 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     WSYNC();
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
-        auto a_gt = [&](int m, int k) { const int kk = k - 6 * mt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * m + kk, P_GCOL); };
+        auto a_gt = [=](int m, int k) { const int kk = k - 6 * mt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * m + kk, P_GCOL); };
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            auto b_wg = [&](int k, int n) { return ldz(L, k < 12, C_WG + 32 * k + 16 * nt + n, C_WG); };
+            auto b_wg = [=](int k, int n) { return ldz(L, k < 12, C_WG + 32 * k + 16 * nt + n, C_WG); };
             const v4d pp = mfma_tile<3>(a_gt, b_wg);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -1304,6 +1334,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
 #define STAMP(i) do { if (dbg && LANE == 0) dbg[4000 + (i)] = (double)clock64(); } while (0)
     STAMP(0);
+    const RefPrefetch pre = prefetch_refs(P, inst, t);
     phase_fk(L, P.gcol + 228);
     STAMP(1);
     phase_com_x(L);
@@ -1320,7 +1351,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     STAMP(5);
     phase_jacobian(L);
     STAMP(6);
-    flags |= phase_refs(L, P, inst, t, k_out, &ph);
+    flags |= phase_refs(L, P, inst, t, pre, k_out, &ph);
     STAMP(7);
     flags |= phase_qp(L, P, ph, Fmask, iters_out, dbg);
     STAMP(8);
