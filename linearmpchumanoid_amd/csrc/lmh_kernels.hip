@@ -31,7 +31,10 @@
 #include "lmh_device.h"
 #include "../../include/lmh.h"
 
-#define WSYNC() __syncthreads()
+// Wave-level fence: orders this wave's LDS traffic for the compiler; the LDS unit executes one wave's
+// instructions in issue order, so no s_waitcnt / s_barrier is needed between a lane's store and another
+// lane's load of the same wave.
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // ------------------------------------------------------------------ constant tables
 #define CPI2 6.123233995736766e-17   // libm's cos(-pi/2) for the reference's pi literal (theta[24], Robot.cpp:87)
