@@ -207,18 +207,121 @@ __device__ __forceinline__ double bcast_lane(double x, int l)     // l is a comp
     return __hiloint2double(hi, lo);
 }
 
+// ---- DPP row broadcast (gfx90a+: 64-bit DPP with row_newbcast): lane l of every 16-lane row reads lane C of
+// its own row.  One instruction, no SGPR round trip (v_readlane needs two per double plus the VALU->SGPR hazard).
+extern "C" __device__ double lmh_update_dpp_f64(double, double, int, int, int, bool) __asm("llvm.amdgcn.update.dpp.f64");
+template <int C>
+__device__ __forceinline__ double bcast16(double x)               // compiler-visible v_mov_b64_dpp (hazards handled by llc)
+{
+    return lmh_update_dpp_f64(x, x, 0x150 + C, 0xf, 0xf, true);
+}
+// acc_k += bcast16<C0 + k>(src) * m for k < K, as ONE asm block of v_fmac_f64_dpp: the leading s_nop covers the
+// "VALU write -> DPP read" hazard on src for whatever the compiler placed before the block; inside the block
+// nothing writes src.  Must run with a full exec mask (wave-uniform control flow only).
+#define LMH_FD(k, s, m, c) "v_fmac_f64_dpp %" #k ", %" #s ", %" #m " row_newbcast:%" #c " row_mask:0xf bank_mask:0xf\n\t"
+template <int C0, int K, int N>
+__device__ __forceinline__ void dpp_fmac_cols(double (&a)[N], double src, double m)
+{
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "chunk size");
+    if constexpr (K == 8)
+        asm volatile("s_nop 1\n\t" LMH_FD(0, 8, 9, 10) LMH_FD(1, 8, 9, 11) LMH_FD(2, 8, 9, 12) LMH_FD(3, 8, 9, 13)
+                     LMH_FD(4, 8, 9, 14) LMH_FD(5, 8, 9, 15) LMH_FD(6, 8, 9, 16) LMH_FD(7, 8, 9, 17)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]), "+v"(a[C0 + 4]), "+v"(a[C0 + 5]), "+v"(a[C0 + 6]), "+v"(a[C0 + 7])
+                     : "v"(src), "v"(m), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3), "n"(C0 + 4), "n"(C0 + 5), "n"(C0 + 6), "n"(C0 + 7));
+    else if constexpr (K == 4)
+        asm volatile("s_nop 1\n\t" LMH_FD(0, 4, 5, 6) LMH_FD(1, 4, 5, 7) LMH_FD(2, 4, 5, 8) LMH_FD(3, 4, 5, 9)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3])
+                     : "v"(src), "v"(m), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
+    else if constexpr (K == 2)
+        asm volatile("s_nop 1\n\t" LMH_FD(0, 2, 3, 4) LMH_FD(1, 2, 3, 5)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]) : "v"(src), "v"(m), "n"(C0), "n"(C0 + 1));
+    else
+        asm volatile("s_nop 1\n\t" LMH_FD(0, 1, 2, 3) : "+v"(a[C0]) : "v"(src), "v"(m), "n"(C0));
+}
+// a[c] += bcast16<c>(src) * m for c in [C0, N)
+template <int C0, int N>
+__device__ __forceinline__ void dpp_fmac_tail(double (&a)[N], double src, double m)
+{
+    constexpr int R = N - C0;
+    if constexpr (R >= 8) { dpp_fmac_cols<C0, 8>(a, src, m); dpp_fmac_tail<C0 + 8>(a, src, m); }
+    else if constexpr (R >= 4) { dpp_fmac_cols<C0, 4>(a, src, m); dpp_fmac_tail<C0 + 4>(a, src, m); }
+    else if constexpr (R >= 2) { dpp_fmac_cols<C0, 2>(a, src, m); dpp_fmac_tail<C0 + 2>(a, src, m); }
+    else if constexpr (R == 1) { dpp_fmac_cols<C0, 1>(a, src, m); }
+}
+// b[r] += bcast16<J>(b[r]) * m for r < M (each right-hand side broadcasts its own lane-J entry)
+#define LMH_FS(k, m, c) "v_fmac_f64_dpp %" #k ", %" #k ", %" #m " row_newbcast:%" #c " row_mask:0xf bank_mask:0xf\n\t"
+template <int J, int M>
+__device__ __forceinline__ void dpp_fmac_rhs(double (&b)[M], double m)
+{
+    static_assert(M == 1 || M == 6 || M == 7, "right-hand-side counts in use");
+    if constexpr (M == 1)
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 1, 2) : "+v"(b[0]) : "v"(m), "n"(J));
+    else if constexpr (M == 6)
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 6, 7) LMH_FS(1, 6, 7) LMH_FS(2, 6, 7) LMH_FS(3, 6, 7) LMH_FS(4, 6, 7) LMH_FS(5, 6, 7)
+                     : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]) : "v"(m), "n"(J));
+    else
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 7, 8) LMH_FS(1, 7, 8) LMH_FS(2, 7, 8) LMH_FS(3, 7, 8) LMH_FS(4, 7, 8) LMH_FS(5, 7, 8) LMH_FS(6, 7, 8)
+                     : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]) : "v"(m), "n"(J));
+}
+
+// One pivot of the row-per-lane LDL' for N <= 16 (all rows inside DPP row 0), then the next (compile-time recursion).
+template <int J, int N, int M>
+__device__ __forceinline__ void ldl16_forward(double (&a)[N], double (&b)[M], unsigned live, int lane, int &bad, double &myinv)
+{
+    if constexpr (J < N) {
+        if ((live >> J) & 1u) {                                   // wave-uniform
+            double d = bcast16<J>(a[J]);
+            d = (lane < 16) ? d : 1.0;                            // DPP rows 1..3 hold no matrix rows
+            if (!(d > 0.0)) bad = 1;
+            const double invd = fast_rcp(d);
+            const double f = a[J] * invd;                         // L_iJ in lanes i > J
+            const double nfm = (lane > J) ? -f : 0.0;
+            if (lane == J) myinv = invd;
+            dpp_fmac_tail<J + 1>(a, a[J], -f);                    // a[c] -= f * (d_J L_cJ held by lane c)
+            dpp_fmac_rhs<J>(b, nfm);                              // forward substitution
+            if (lane > J) a[J] = f;
+        }
+        ldl16_forward<J + 1>(a, b, live, lane, bad, myinv);
+    }
+}
+template <int J, int N, int M>
+__device__ __forceinline__ void ldl16_backward(double (&b)[M], unsigned live, int lane, const double *Ls)
+{
+    if constexpr (J > 0) {
+        if ((live >> J) & 1u) {
+            const double nl = (lane < J) ? -Ls[J * (N + 1) + lane] : 0.0;
+            dpp_fmac_rhs<J>(b, nl);
+        }
+        ldl16_backward<J - 1, N>(b, live, lane, Ls);
+    }
+}
+
 // Register-resident LDL' solve of an SPD system with M right-hand sides, N <= 32.
 // Lane i < N holds row i of the matrix in a[] (entries a[c], c <= i, are used; rows / columns whose
 // bit is clear in `live` must be zero and are skipped) and its rhs entries in b[].  The pivot column
-// is broadcast with v_readlane (no LDS round trip inside the factorisation); the rows of L are parked
-// once in Ls (row stride N+1, conflict free) for the backward substitution.  On exit b[r] of lane i
-// holds x_i.  Returns non-zero (wave-uniform) if a pivot was not positive.
+// is broadcast lane to lane (DPP row broadcast for N <= 16, v_readlane above; no LDS round trip inside the
+// factorisation); the rows of L are parked once in Ls (row stride N+1, conflict free) for the backward
+// substitution.  On exit b[r] of lane i holds x_i.  Returns non-zero (wave-uniform) if a pivot was not positive.
 template <int N, int M>
 __device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], unsigned live, double *Ls)
 {
     const int lane = LANE;
     int bad = 0;
     double myinv = 0.0;                                           // 1 / d_lane (0 on rows that are not live)
+    if constexpr (N <= 16) {
+        ldl16_forward<0>(a, b, live, lane, bad, myinv);
+        bad = __builtin_amdgcn_readfirstlane(bad);
+#pragma unroll
+        for (int r = 0; r < M; r++) b[r] *= myinv;                // w = D^-1 z
+        WSYNC();
+        if (lane < N) {
+#pragma unroll
+            for (int c = 0; c < N - 1; c++) Ls[lane * (N + 1) + c] = a[c];          // L[lane][c], c < lane
+        }
+        WSYNC();
+        ldl16_backward<N - 1, N>(b, live, lane, Ls);
+        return bad;
+    }
 #pragma unroll
     for (int j = 0; j < N; j++) {
         if (!((live >> j) & 1u)) continue;                        // wave-uniform

@@ -11,8 +11,12 @@ ctl = BatchedController(B, default_config(dt=1e-3, time_horizon=0.016, z_com=ik[
 ctl.set_refs_stance(2.0, 2)
 v = perturbed_velocities(B)
 st = ctl.new_state(np.array(ik['q']), v, t=0.0)
+pre = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # rollout ticks before the stamped evaluation (realistic active sets)
+status = ctl.new_status(); out = ctl.new_out()
+if pre:
+    ctl.rollout(st, pre, out, status)
 for rep in range(3):
-    out, status, dbg = ctl.stand_step(st, debug=True)
+    out, status, dbg = ctl.stand_step(st, out=out, status=status, debug=True)   # status carries the active set (warm start)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy(); s = status.cpu().numpy()
 names = ['fk', 'com_x', 'dump', 'newton_euler', 'crba', 'jacobian', 'refs', 'qp', 'outputs']
