@@ -35,6 +35,15 @@
 // instructions in issue order, so no s_waitcnt / s_barrier is needed between a lane's store and another
 // lane's load of the same wave.
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// The fused rollout kernel gives every robot TWO waves (NW = 2) that share its LDS: independent pieces of one
+// evaluation (Newton-Euler | CRBA, the two reference chains, the MFMA tiles of the QP set-up) run side by side
+// and join at workgroup barriers; the sequential factorisations stay on wave 0.  NW = 1 (the evaluation, IK and
+// model kernels) degenerates to the single-wave schedule: the join is the wave fence.
+template <int NW>
+__device__ __forceinline__ void bsync()
+{
+    if constexpr (NW == 1) WSYNC(); else __syncthreads();
+}
 
 // ------------------------------------------------------------------ constant tables
 #define CPI2 6.123233995736766e-17   // libm's cos(-pi/2) for the reference's pi literal (theta[24], Robot.cpp:87)
@@ -119,6 +128,7 @@ enum {
     A_FB = S0 + 1788, // 2 x 24 x 6
     A_XN = S0 + 2076, // 2 x 2 x 18
     A_JL = S0 + 2148, // 2 x 6 x 12
+    A_XR = S0 + 2292, // 5 x 36 chain-root contributions to Ic_0 (CRBA; disjoint from the Jacobian's A_XN / A_JL)
     // ---- phase B (Woodbury + Schur)
     B_U = S0 + 0,     // 18 x 30
     B_K = S0 + 540,   // 25 x 19
@@ -141,7 +151,7 @@ enum {
 // 256 AGPR + scratch spills (~100 MB of scratch traffic per launch) for no gain.
 __device__ __forceinline__ int lane_opaque()
 {
-    int l = (int)threadIdx.x;
+    int l = (int)(threadIdx.x & 63u);
     asm volatile("" : "+v"(l));
     return l;
 }
@@ -443,28 +453,35 @@ __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
 
 // Robot::computeCoM (Robot.cpp:225-238) + parentTransMatrix/allVelocityMatrices/velocityMatrix
 // (Robot.cpp:276-298, generalizedFunctions.cpp:11-27: R' used as inverse, kept).
-__device__ __forceinline__ void phase_com_x(double *L)
+// NW = 2: wave 0 owns the CoM, frames 0..13 and the persistent copies, wave 1 frames 14..27 (B of a frame needs
+// only that frame's E, p, so the two halves never wait for each other; the caller joins them).
+template <int NW>
+__device__ __forceinline__ void phase_com_x(double *L, int wid)
 {
     const int lane = LANE;
-    double cx = 0, cy = 0, cz = 0;
-    if (lane < 28) {
-        const double *T = L + A_T + 12 * lane, *mo = L + P_MODEL + LMH_BODY_STRIDE * lane;
-        const double m = mo[12];
-        if (m != 0.0) {
-            // joint-frame com = (m c)/m is not stored; the model keeps m*c, so use it directly
-            cx = T[0] * mo[9] + T[1] * mo[10] + T[2] * mo[11] + m * T[3];
-            cy = T[4] * mo[9] + T[5] * mo[10] + T[6] * mo[11] + m * T[7];
-            cz = T[8] * mo[9] + T[9] * mo[10] + T[10] * mo[11] + m * T[11];
+    if (wid == 0) {
+        double cx = 0, cy = 0, cz = 0;
+        if (lane < 28) {
+            const double *T = L + A_T + 12 * lane, *mo = L + P_MODEL + LMH_BODY_STRIDE * lane;
+            const double m = mo[12];
+            if (m != 0.0) {
+                // joint-frame com = (m c)/m is not stored; the model keeps m*c, so use it directly
+                cx = T[0] * mo[9] + T[1] * mo[10] + T[2] * mo[11] + m * T[3];
+                cy = T[4] * mo[9] + T[5] * mo[10] + T[6] * mo[11] + m * T[7];
+                cz = T[8] * mo[9] + T[9] * mo[10] + T[10] * mo[11] + m * T[11];
+            }
+        }
+        cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
+        if (lane == 0) {
+            const double mass = L[P_MODEL + 392];
+            L[P_COM] = cx / mass; L[P_COM + 1] = cy / mass; L[P_COM + 2] = cz / mass;
         }
     }
-    cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
-    if (lane == 0) {
-        const double mass = L[P_MODEL + 392];
-        L[P_COM] = cx / mass; L[P_COM + 1] = cy / mass; L[P_COM + 2] = cz / mass;
-    }
     SUBSTAMP(2);
-    for (int e = lane; e < 27 * 12; e += 64) {                     // frames 1..27: E = Rp' Ri, p = Rp' pi + (-Rp') pp
-        const int i = 1 + e / 12, el = e % 12;
+    const int f_lo = (NW == 2 && wid == 1) ? 14 : 1;               // first frame of the E, p loop
+    const int f_n = (NW == 1) ? 27 : (wid ? 14 : 13);
+    for (int e = lane; e < f_n * 12; e += 64) {                    // frames 1..27: E = Rp' Ri, p = Rp' pi + (-Rp') pp
+        const int i = f_lo + e / 12, el = e % 12;
         const bool isE = el < 9;
         const int a = isE ? el / 3 : el - 9, col = isE ? el % 3 : 3;
         const double *Ti = L + A_T + 12 * i + col, *Tp = L + A_T + 12 * f_parent(i);
@@ -473,37 +490,40 @@ __device__ __forceinline__ void phase_com_x(double *L)
         const double s2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
         L[(isE ? A_XE + 9 * i + el : A_XP + 3 * i + (el - 9))] = isE ? s1 : s1 + s2;
     }
-    if (lane < 12) {                                               // frame 0: E = R0, p = p0
+    if (wid == 0 && lane < 12) {                                   // frame 0: E = R0, p = p0
         const double *T0 = L + A_T;
         if (lane < 9) L[A_XE + lane] = T0[(lane / 3) * 4 + lane % 3];
         else L[A_XP + (lane - 9)] = T0[(lane - 9) * 4 + 3];
     }
     WSYNC();
     SUBSTAMP(3);
-    for (int e = lane; e < 28 * 9; e += 64) {
-        const int i = e / 9, a = (e % 9) / 3, b = e % 3;
+    const int b_lo = (NW == 2 && wid == 1) ? 14 : 0, b_n = (NW == 1) ? 28 : 14;
+    for (int e = lane; e < b_n * 9; e += 64) {
+        const int i = b_lo + e / 9, a = (e % 9) / 3, b = e % 3;
         const double *E = L + A_XE + 9 * i, *p = L + A_XP + 3 * i;
         double val;                                               // B = (-E') [p]x
         if (b == 0) val = (-E[3 + a]) * p[2] + E[6 + a] * p[1];
         else if (b == 1) val = E[a] * p[2] + (-E[6 + a]) * p[0];
         else val = (-E[a]) * p[1] + E[3 + a] * p[0];
-        L[A_XB + e] = val;
+        L[A_XB + 9 * b_lo + e] = val;
     }
     WSYNC();
     SUBSTAMP(4);
-    // persistent copies: T0, T7, T14, X0
-    if (lane < 36) L[P_TB + lane] = L[A_T + 12 * ((lane < 12) ? 0 : (lane < 24) ? 7 : 14) + lane % 12];
-    if (lane < 21) L[P_X0 + lane] = (lane < 9) ? L[A_XE + lane] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XB + lane - 12];
-    // base-frame reordered velocities, stale (Robot::v_) and fresh: swapBaseVelocityAndRefToWorldFrame
-    if (lane < 60) {
-        const int which = lane / 30, i = lane % 30;
-        const double *v = L + (which ? P_V : P_VP);
-        double val;
-        if (i < 6) {
-            const double m[6] = {v[3], v[4], v[5], v[0], v[1], v[2]};
-            val = x_mot(L + A_XE, L + A_XB, m, i);
-        } else val = v[i];
-        L[(which ? P_VHN : P_VHS) + i] = val;
+    if (wid == 0) {
+        // persistent copies: T0, T7, T14, X0
+        if (lane < 36) L[P_TB + lane] = L[A_T + 12 * ((lane < 12) ? 0 : (lane < 24) ? 7 : 14) + lane % 12];
+        if (lane < 21) L[P_X0 + lane] = (lane < 9) ? L[A_XE + lane] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XB + lane - 12];
+        // base-frame reordered velocities, stale (Robot::v_) and fresh: swapBaseVelocityAndRefToWorldFrame
+        if (lane < 60) {
+            const int which = lane / 30, i = lane % 30;
+            const double *v = L + (which ? P_V : P_VP);
+            double val;
+            if (i < 6) {
+                const double m[6] = {v[3], v[4], v[5], v[0], v[1], v[2]};
+                val = x_mot(L + A_XE, L + A_XB, m, i);
+            } else val = v[i];
+            L[(which ? P_VHN : P_VHS) + i] = val;
+        }
     }
     WSYNC();
 }
@@ -697,7 +717,7 @@ __device__ __forceinline__ void phase_crba(double *L)
                 if (on) { ic[0] = bp3[0] + z[0]; ic[1] = bp3[1] + z[1]; ic[2] = bp3[2] + z[2]; }
             } else if (on) {                                       // depth 1: park the contribution to the base
                 const int slot = (ch == 4) ? 0 : 4 - ch;           // reference order head, LA, RA, LL, RL
-                double *o = L + A_XN + 36 * slot + 6 * r + 3 * cb;
+                double *o = L + A_XR + 36 * slot + 6 * r + 3 * cb;
                 o[0] = z[0]; o[1] = z[1]; o[2] = z[2];
             }
         }
@@ -709,7 +729,7 @@ __device__ __forceinline__ void phase_crba(double *L)
         body_row3(L + P_MODEL, r, cb, acc);
 #pragma unroll
         for (int sl = 0; sl < 5; sl++) {
-            const double *o = L + A_XN + 36 * sl + 6 * r + 3 * cb;
+            const double *o = L + A_XR + 36 * sl + 6 * r + 3 * cb;
             acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
         }
         double *mt = L + P_MTOP + 30 * r + 3 * cb;
@@ -832,11 +852,12 @@ __device__ __forceinline__ RefPrefetch prefetch_refs(const LmhDevParams &P, int 
     return r;
 }
 
-__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre, int *k_out, int *phase_out)
+// The references form two independent chains: (A) AG, AGpqp -> momentum -> MPC -> PDMomentumAcc needs the mass
+// matrix; (B) foot velocities, PDJointsAcc -> PDFeetAcc needs the Jacobian.  NW = 1 interleaves them step by
+// step in one wave; NW = 2 gives chain A to wave 1 and chain B to wave 0 (the caller joins them).
+__device__ __forceinline__ void refs_ag(double *L, double mass)
 {
     const int lane = LANE;
-    int flags = 0;
-    const double mass = L[P_MODEL + 392];
     for (int e = lane; e < 180; e += 64) {
         const int r = e / 30, c = e % 30;
         const double *T0 = L + P_TB, *Mt = L + P_MTOP + c;
@@ -865,13 +886,19 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         } else val = T0[4 * r] * cg[3] + T0[4 * r + 1] * cg[4] + T0[4 * r + 2] * cg[5];
         L[P_AGPQP + lane] = val;
     }
-    WSYNC();
-    SUBSTAMP(12);
+}
+__device__ __forceinline__ void refs_momentum(double *L, double mass)
+{
+    const int lane = LANE;
     if (lane < 6) {                                                // h = AG vhat (fresh velocity)
         double s = 0.0;
         for (int c = 0; c < 30; c++) s += L[P_AG + 30 * lane + c] * L[P_VHN + c];
         if (lane < 3) L[P_ANGM + lane] = s; else L[P_COMV + lane - 3] = s / mass;
     }
+}
+__device__ __forceinline__ void refs_vfoot_pdjoints(double *L, const LmhDevParams &P)
+{
+    const int lane = LANE;
     if (lane >= 8 && lane < 20) {                                  // foot velocities J vhat
         const int row = lane - 8, ft = row / 6;
         const double *J = L + P_JC + 72 * ft + 12 * (row % 6);
@@ -885,8 +912,11 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         const double val = P.kp_joints * (qdes_of(i) - L[P_Q + i]) + P.kd_joints * (0.0 - L[P_V + i]);
         L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
     }
-    WSYNC();
-    SUBSTAMP(13);
+}
+__device__ __forceinline__ int refs_mpc(double *L, const LmhDevParams &P, int inst, const RefPrefetch &pre, double *zcom_out)
+{
+    const int lane = LANE;
+    int flags = 0;
     // ---- MPC: u0 = -K (Px x_k - z[k : k+N+1])
     const int N = P.horizon;
     const int k = pre.k;
@@ -922,10 +952,12 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
             L[P_MPC + 7] = uy;
         }
     }
-    const int ph = pre.ph;
-    *k_out = k; *phase_out = ph;
-    WSYNC();
-    SUBSTAMP(14);
+    *zcom_out = zcom;
+    return flags;
+}
+__device__ __forceinline__ void refs_pd_momentum(double *L, const LmhDevParams &P, double mass, double zcom)
+{
+    const int lane = LANE;
     if (lane < 3) {                                                // PDMomentumAcc, controller.cpp:310-325
         const double posRef = (lane == 0) ? L[P_MPC + 2] : (lane == 1) ? L[P_MPC + 5] : zcom;
         const double velRef = (lane == 0) ? L[P_MPC + 3] : (lane == 1) ? L[P_MPC + 6] : 0.0;
@@ -933,6 +965,10 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         L[P_HREF + 3 + lane] = mass * (P.kp_mom * (posRef - L[P_COM + lane]) + P.kd_mom * (velRef - L[P_COMV + lane]) + accRef);
         L[P_HREF + lane] = P.kd_mom * (0.0 - L[P_ANGM + lane]);
     }
+}
+__device__ __forceinline__ void refs_pd_feet(double *L, const LmhDevParams &P, int inst, double t, int k)
+{
+    const int lane = LANE;
     if (lane >= 8 && lane < 10) {                                  // orientation error, controller.cpp:344-353
         const int ft = lane - 8;
         const double *T = L + P_TB + 12 * (1 + ft);
@@ -981,7 +1017,45 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         const double ve = vv - L[P_VFOOT + 6 * ft + 3 + ax];
         L[P_FREF + 6 * ft + 3 + ax] = P.kp_feet * pe + P.kd_feet * ve + av;
     }
-    WSYNC();
+}
+
+template <int NW>
+__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre, int wid, int *k_out, int *phase_out)
+{
+    int flags = 0;
+    const double mass = L[P_MODEL + 392];
+    double zcom = 0.0;
+    *k_out = pre.k; *phase_out = pre.ph;
+    if (pre.k < 0 || pre.k + P.horizon >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;    // on every wave (wave 0 reports)
+    if constexpr (NW == 1) {
+        refs_ag(L, mass);
+        WSYNC();
+        SUBSTAMP(12);
+        refs_momentum(L, mass);
+        refs_vfoot_pdjoints(L, P);
+        WSYNC();
+        SUBSTAMP(13);
+        flags |= refs_mpc(L, P, inst, pre, &zcom);
+        WSYNC();
+        SUBSTAMP(14);
+        refs_pd_momentum(L, P, mass, zcom);
+        refs_pd_feet(L, P, inst, t, pre.k);
+        WSYNC();
+    } else if (wid == 1) {                                         // chain A
+        refs_ag(L, mass);
+        WSYNC();
+        refs_momentum(L, mass);
+        WSYNC();
+        flags |= refs_mpc(L, P, inst, pre, &zcom);
+        WSYNC();
+        refs_pd_momentum(L, P, mass, zcom);
+        WSYNC();
+    } else {                                                       // chain B
+        refs_vfoot_pdjoints(L, P);
+        WSYNC();
+        refs_pd_feet(L, P, inst, t, pre.k);
+        WSYNC();
+    }
     return flags;
 }
 
@@ -1161,8 +1235,8 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
 
 // QP set-up (controller.cpp:94-132 Hessian/gradient and the equality blocks of :388-436) down to the cone
 // problem data P, qv; NU = rows of U = [AG ; J] that carry weight (15 when the angular-momentum weight is 0).
-template <int NU>
-__device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double *dbgp)
+template <int NU, int NW>
+__device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wid, double *dbgp)
 {
     const int lane = LANE;
     int flags = 0;
@@ -1170,11 +1244,11 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     constexpr int nU = NU, r0 = 18 - NU;
     const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
     const int tr = lane & 15, tq = lane >> 4;                      // MFMA result: rows tq + 4 reg, column tr
-    for (int e = lane; e < nU * 30; e += 64) {
+    for (int e = lane + 64 * wid; e < nU * 30; e += 64 * NW) {
         const int r = r0 + e / 30, c = e % 30;
         L[B_U + e] = (r < 6) ? L[P_AG + 30 * r + c] : jdense(L, r - 6, c);
     }
-    if (lane < nU) {                                               // Om_r * beta_r , 1 / Om_r , beta_r
+    if (wid == 0 && lane < nU) {                                   // Om_r * beta_r , 1 / Om_r , beta_r
         const int rr = r0 + lane;
         const double om = (rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot;
         const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
@@ -1184,12 +1258,12 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
     }
     // bp' = [-qref | D^-1 Mb']  (the U' Om beta part of g_a is folded into the right-hand side below:
     // U bp_g = Cm ob - beta - U qref  and  Y_g = D^-1 U'(ob - t_g) - qref; controller.cpp:127-132)
-    for (int e = lane; e < 210; e += 64) {
+    for (int e = lane + 64 * wid; e < 210; e += 64 * NW) {
         const int i = e / 7, cidx = e % 7;
         const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
         L[B_BP + e] = (cidx == 0) ? -L[P_QREF + i] : L[P_MTOP + 30 * (cidx - 1) + i] * iDi;
     }
-    WSYNC();
+    bsync<NW>();
     if (dbgp && LANE == 0) dbgp[4070] = (double)clock64();
     // ---- Cm = Om^-1 + U D^-1 U'  and  V = U bp'  on the matrix cores (K = 30 padded to 32)
     const int ld = 19;
@@ -1202,9 +1276,11 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
             return ldz(L, n < nU && k < 30, B_U + 30 * n + k, B_U) * sc;
         };
         auto b_bp = [=](int k, int n) { return ldz(L, n < 7 && k < 30, B_BP + 7 * k + n, B_BP); };
-        const v4d cm = mfma_tile<8>(a_u, b_ud);
-        const v4d vv = mfma_tile<8>(a_u, b_bp);
-        if constexpr (NU > 16) {                                             // rows/cols 16, 17 (angular-momentum weight set): plain loops
+        const bool do_cm = (NW == 1) || (wid == 0), do_vv = (NW == 1) || (wid == 1);    // NW = 2: one tile per wave
+        v4d cm = {0.0, 0.0, 0.0, 0.0}, vv = {0.0, 0.0, 0.0, 0.0};
+        if (do_cm) cm = mfma_tile<8>(a_u, b_ud);
+        if (do_vv) vv = mfma_tile<8>(a_u, b_bp);
+        if constexpr (NU > 16) if (wid == 0) {                                             // rows/cols 16, 17 (angular-momentum weight set): plain loops
             for (int e = lane; e < 2 * 18; e += 64) {
                 const int r = 16 + e / 18, c = e % 18;
                 if (c <= r) {
@@ -1223,12 +1299,13 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int row = tq + 4 * g;
-            if (row < nU && tr <= row) L[B_K + ld * row + tr] = cm[g] + ((row == tr) ? L[B_OB + 18 + row] : 0.0);
-            if (row < nU && tr < 7) L[B_K + ld * (nU + tr) + row] = vv[g];
-            if (row < nU && tr < nU) L[B_CF + 18 * row + tr] = cm[g] + ((row == tr) ? L[B_OB + 18 + row] : 0.0);   // full copy for Cm ob
+            if (do_cm && row < nU && tr <= row) L[B_K + ld * row + tr] = cm[g] + ((row == tr) ? L[B_OB + 18 + row] : 0.0);
+            if (do_vv && row < nU && tr < 7) L[B_K + ld * (nU + tr) + row] = vv[g];
+            if (do_cm && row < nU && tr < nU) L[B_CF + 18 * row + tr] = cm[g] + ((row == tr) ? L[B_OB + 18 + row] : 0.0);   // full copy for Cm ob
         }
     }
-    WSYNC();
+    bsync<NW>();
+    if (wid == 0) {                                                // wave 0: right-hand side fix-up and the nU x nU factorisation
     if (lane < nU) {                                               // V_g += Cm ob - beta
         double sacc = -L[B_OB + 36 + lane];
         for (int c = 0; c < nU; c++) {
@@ -1254,13 +1331,15 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
             for (int r = 0; r < 7; r++) L[B_K + ld * (nU + r) + lane] = bb[r];
         }
     }
-    WSYNC();
+    }
+    bsync<NW>();
     if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
     // ---- Y = bp' - D^-1 U' t'   (30 x 7; two row tiles, K = nU padded to 20)
     {
         auto b_t = [=](int k, int n) { return ldz(L, k < nU && n < 7, B_K + ld * (nU + n) + k, B_K); };
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
+            if (NW == 2 && mt != wid) continue;                    // one row tile per wave
             auto a_ut = [=](int m, int k) { const int i = 16 * mt + m; return ldz(L, i < 30 && k < nU, B_U + 30 * k + i, B_U); };
             const v4d yy = mfma_tile<5>(a_ut, b_t);
 #pragma unroll
@@ -1270,9 +1349,10 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
             }
         }
     }
-    WSYNC();
+    bsync<NW>();
     if (dbgp && LANE == 0) dbgp[4010] = (double)clock64();
     // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g  (one tile, K = 30 padded to 32); Si = S^-1
+    if (wid == 0) {                                                // a dependent chain of small products: wave 0
     {
         auto a_m = [=](int m, int k) { return ldz(L, m < 6 && k < 30, P_MTOP + 30 * m + k, P_MTOP); };
         auto b_y = [=](int k, int n) { return ldz(L, n < 7 && k < 30, P_Y + 7 * k + n, P_Y); };
@@ -1316,7 +1396,8 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
             if (row < 12 && tr == 12) L[P_H12 + row] = ww[g];
         }
     }
-    WSYNC();
+    }
+    bsync<NW>();
     if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
     // ---- cone QP data: WG = W G (12 x 32), Pm = G' WG + eps I (32 x 32), qv = G' h ; G[k][j] is the
     //      generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
@@ -1324,21 +1405,23 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
         auto a_w = [=](int m, int k) { return ldz(L, m < 12 && k < 12, P_W + 12 * m + k, P_W); };
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
+            if (NW == 2 && nt != wid) continue;                    // one column tile per wave
             auto b_g = [=](int k, int n) { const int kk = k - 6 * nt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * n + kk, P_GCOL); };
             const v4d wg = mfma_tile<3>(a_w, b_g);
 #pragma unroll
             for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12) L[C_WG + 32 * row + 16 * nt + tr] = wg[g]; }
         }
     }
-    if (lane < 32) {
+    if (wid == 0 && lane < 32) {
         const int o = 6 * (lane / 16);
         double sacc = 0.0;
         for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
         L[P_QV + lane] = sacc;
     }
-    WSYNC();
+    bsync<NW>();
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
+        if (NW == 2 && mt != wid) continue;                        // two of the four tiles per wave
         auto a_gt = [=](int m, int k) { const int kk = k - 6 * mt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * m + kk, P_GCOL); };
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
@@ -1351,15 +1434,17 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, double
             }
         }
     }
-    WSYNC();
+    bsync<NW>();
     return flags;
 }
 
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
-__device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
+template <int NW>
+__device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
 {
     const int lane = LANE;
-    int flags = (P.w_com_ang == 0.0) ? qp_setup<15>(L, P, dbgp) : qp_setup<18>(L, P, dbgp);
+    int flags = (P.w_com_ang == 0.0) ? qp_setup<15, NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
+    if (NW == 2 && wid != 0) return 0;                             // the active-set iteration and the recovery are sequential: wave 0
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
     // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
     unsigned forced = 0u;
@@ -1433,17 +1518,23 @@ __device__ __forceinline__ void phase_outputs(double *L)
     WSYNC();
 }
 
-// one controller evaluation on the state in L[P_Q], L[P_V], L[P_VP] at time t
-__device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
+// one controller evaluation on the state in L[P_Q], L[P_V], L[P_VP] at time t.  NW = 2: both waves of the robot
+// call this with their wave index; every bsync below is reached by both (uniform control flow), all other fences
+// are wave-local.  Wave 1 never touches P_Q / P_V / the QP scratch after its last bsync, so wave 0 may run ahead
+// into the next evaluation's forward kinematics.
+template <int NW>
+__device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
 {
     int flags = 0, ph = 0;
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
 #define STAMP(i) do { if (dbg && LANE == 0) dbg[4000 + (i)] = (double)clock64(); } while (0)
     STAMP(0);
     const RefPrefetch pre = prefetch_refs(P, inst, t);
-    phase_fk(L, P.gcol + 228);
+    if (wid == 0) phase_fk(L, P.gcol + 228);
+    bsync<NW>();
     STAMP(1);
-    phase_com_x(L);
+    phase_com_x<NW>(L, wid);
+    bsync<NW>();
     STAMP(2);
     if (dbg) {
         for (int e = LANE; e < 336; e += 64) dbg[e] = L[A_T + e];
@@ -1451,17 +1542,24 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         for (int e = LANE; e < 84; e += 64) dbg[588 + e] = L[A_XP + e];
     }
     STAMP(3);
-    phase_newton_euler(L);
-    STAMP(4);
-    phase_crba(L);
-    STAMP(5);
-    phase_jacobian(L);
+    if constexpr (NW == 1) {
+        phase_newton_euler(L);
+        STAMP(4);
+        phase_crba(L);
+        STAMP(5);
+        phase_jacobian(L);
+    } else {
+        if (wid == 0) { phase_newton_euler(L); phase_jacobian(L); }    // LDS regions of the three are disjoint
+        else phase_crba(L);
+    }
+    bsync<NW>();
     STAMP(6);
-    flags |= phase_refs(L, P, inst, t, pre, k_out, &ph);
+    flags |= phase_refs<NW>(L, P, inst, t, pre, wid, k_out, &ph);
+    bsync<NW>();
     STAMP(7);
-    flags |= phase_qp(L, P, ph, Fmask, iters_out, dbg);
+    flags |= phase_qp<NW>(L, P, ph, wid, Fmask, iters_out, dbg);
     STAMP(8);
-    phase_outputs(L);
+    if (wid == 0) phase_outputs(L);
     STAMP(9);
     if (dbg) {
         const int lane = LANE;
@@ -1547,7 +1645,7 @@ __global__ void __launch_bounds__(64) lmh_eval_kernel(LmhDevParams P, double *st
     int k = 0, iters = 0;
     SET_GDBG(DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
     WSYNC();
-    const int flags = controller_eval(L, P, inst, t, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    const int flags = controller_eval<1>(L, P, inst, t, 0, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
     store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
     if (LANE < 30) st[60 + LANE] = L[P_V + LANE];                  // Robot::v_ <- dq (controller.cpp:59)
     if (LANE == 0) {
@@ -1557,74 +1655,91 @@ __global__ void __launch_bounds__(64) lmh_eval_kernel(LmhDevParams P, double *st
 }
 
 // Closed loop of apps/offline/main.cpp:66-122: n_ticks x rk4Step(dynamics) with Clock::step.
-__global__ void __launch_bounds__(64) lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *log, int n_ticks)
+// Workgroup = LMH_ROLLOUT_THREADS = 2 waves per robot (see bsync): 4 robots = 8 waves per CU, two per SIMD, so the
+// kernel is held to 256 registers.  Wave 0 owns the RK4 state (lane i < 60 <-> component i) and everything
+// sequential; wave 1 joins for the phases controller_eval<2> splits.
+__global__ void __launch_bounds__(LMH_ROLLOUT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *log, int n_ticks)
 {
     __shared__ double L[LDS_DOUBLES];
     const int inst = blockIdx.x;
-    if (inst >= P.n_instances) return;
+    if (inst >= P.n_instances) return;                             // workgroup-uniform
     const int lane = LANE;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double *st = state + (size_t)LMH_STATE_STRIDE * inst;
-    load_common(L, P, inst);
-    // lane i < 60 owns state component i (q | v); v_prev lives in LDS between evaluations
     SET_GDBG(nullptr);
-    double x = (lane < 60) ? st[lane] : 0.0;
-    if (lane < 30) L[P_VP + lane] = st[60 + lane];
-    double t = st[90];
-    unsigned F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
-    F = P.warm_start ? ~F : 0xFFFFFFFFu;
+    double x = 0.0, t = st[90];
+    unsigned F = 0xFFFFFFFFu;
+    if (wid == 0) {
+        load_common(L, P, inst);
+        // lane i < 60 owns state component i (q | v); v_prev lives in LDS between evaluations
+        x = (lane < 60) ? st[lane] : 0.0;
+        if (lane < 30) L[P_VP + lane] = st[60 + lane];
+        F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
+        F = P.warm_start ? ~F : 0xFFFFFFFFu;
+    }
+    bsync<2>();
     int k = 0, iters = 0, flags = 0, itmax = 0;
     const double dt = P.dt;
     for (int tick = 0; tick < n_ticks; tick++) {
         double ksum = 0.0, xs = x;
         for (int stage = 0; stage < 4; stage++) {
             const double ts = (stage == 0) ? t : (stage == 3) ? t + dt : t + 0.5 * dt;      // rk4.hpp:12-15
-            WSYNC();
-            if (lane < 60) L[P_Q + lane] = xs;
-            WSYNC();
-            flags |= controller_eval(L, P, inst, ts, &F, &k, &iters, nullptr);
-            itmax = (iters > itmax) ? iters : itmax;
-            // xdot (apps/offline/main.cpp:107-121)
-            double xd = 0.0;
-            if (lane < 60) {
-                if (lane >= 30) xd = L[P_QDD + lane - 30];
-                else if (lane >= 6) xd = L[P_V + lane];
-                else if (lane < 3) {
-                    const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
-                    const double p0 = L[P_Q], p1 = L[P_Q + 1], p2 = L[P_Q + 2];
-                    const double cr = (lane == 0) ? (-w2 * p1 + w1 * p2) : (lane == 1) ? (w2 * p0 - w0 * p2) : (-w1 * p0 + w0 * p1);
-                    xd = L[P_V + lane] + cr;                       // v_classic = v_spatial + w x p
-                } else {
-                    const double sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
-                    const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
-                    const double tp = sp / cp;
-                    xd = (lane == 3) ? (cy / cp) * w0 + (sy / cp) * w1 + 0.0 * w2
-                       : (lane == 4) ? (-sy) * w0 + cy * w1 + 0.0 * w2
-                                     : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
-                }
+            if (wid == 0) {
+                WSYNC();
+                if (lane < 60) L[P_Q + lane] = xs;
+                WSYNC();
             }
-            // Robot::v_ <- dq for the next evaluation
-            WSYNC();
-            if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xs;
-            if (stage == 0) { ksum = xd; xs = x + 0.5 * dt * xd; }
-            else if (stage == 1) { ksum = ksum + 2.0 * xd; xs = x + 0.5 * dt * xd; }
-            else if (stage == 2) { ksum = ksum + 2.0 * xd; xs = x + dt * xd; }
-            else { ksum = ksum + xd; }
+            flags |= controller_eval<2>(L, P, inst, ts, wid, &F, &k, &iters, nullptr);
+            if (wid == 0) {
+                itmax = (iters > itmax) ? iters : itmax;
+                // xdot (apps/offline/main.cpp:107-121)
+                double xd = 0.0;
+                if (lane < 60) {
+                    if (lane >= 30) xd = L[P_QDD + lane - 30];
+                    else if (lane >= 6) xd = L[P_V + lane];
+                    else if (lane < 3) {
+                        const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
+                        const double p0 = L[P_Q], p1 = L[P_Q + 1], p2 = L[P_Q + 2];
+                        const double cr = (lane == 0) ? (-w2 * p1 + w1 * p2) : (lane == 1) ? (w2 * p0 - w0 * p2) : (-w1 * p0 + w0 * p1);
+                        xd = L[P_V + lane] + cr;                   // v_classic = v_spatial + w x p
+                    } else {
+                        const double sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
+                        const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
+                        const double tp = sp / cp;
+                        xd = (lane == 3) ? (cy / cp) * w0 + (sy / cp) * w1 + 0.0 * w2
+                           : (lane == 4) ? (-sy) * w0 + cy * w1 + 0.0 * w2
+                                         : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
+                    }
+                }
+                // Robot::v_ <- dq for the next evaluation
+                WSYNC();
+                if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xs;
+                if (stage == 0) { ksum = xd; xs = x + 0.5 * dt * xd; }
+                else if (stage == 1) { ksum = ksum + 2.0 * xd; xs = x + 0.5 * dt * xd; }
+                else if (stage == 2) { ksum = ksum + 2.0 * xd; xs = x + dt * xd; }
+                else { ksum = ksum + xd; }
+            }
         }
-        x = x + (dt / 6.0) * ksum;                                  // rk4.hpp:17
-        if (log) {
-            double *lg = log + ((size_t)tick * P.n_instances + inst) * 36;
-            if (lane < 24) lg[lane] = L[P_TAU + lane]; else if (lane < 36) lg[lane] = L[P_W12 + lane - 24];
+        if (wid == 0) {
+            x = x + (dt / 6.0) * ksum;                              // rk4.hpp:17
+            if (log) {
+                double *lg = log + ((size_t)tick * P.n_instances + inst) * 36;
+                if (lane < 24) lg[lane] = L[P_TAU + lane]; else if (lane < 36) lg[lane] = L[P_W12 + lane - 24];
+            }
         }
         t += dt;                                                    // Clock::step, Clock.hpp:11
     }
-    WSYNC();
-    store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
-    if (lane < 60) st[lane] = x;
-    if (lane < 30) st[60 + lane] = L[P_VP + lane];
-    if (lane == 0) {
-        st[90] = t;
-        int32_t *s = status + LMH_STATUS_STRIDE * inst;
-        s[0] = k; s[1] = itmax; s[2] = flags; s[3] = (int32_t)(~F);
+    if (wid == 0) {
+        WSYNC();
+        store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
+        if (lane < 60) st[lane] = x;
+        if (lane < 30) st[60 + lane] = L[P_VP + lane];
+        if (lane == 0) {
+            st[90] = t;
+            int32_t *s = status + LMH_STATUS_STRIDE * inst;
+            s[0] = k; s[1] = itmax; s[2] = flags; s[3] = (int32_t)(~F);
+        }
     }
 }
 
@@ -1724,7 +1839,7 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
     int iter = 0;
     for (;;) {
         phase_fk(L, P.gcol + 228);
-        phase_com_x(L);
+        phase_com_x<1>(L, 0);
         phase_jacobian(L);
         // operationalState (:54-70)
         double Qv = 0.0;
@@ -1877,7 +1992,7 @@ __global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P, const doubl
     if (LANE < 60) L[P_V + LANE] = 0.0;
     WSYNC();
     phase_fk(L, P.gcol + 228);
-    phase_com_x(L);
+    phase_com_x<1>(L, 0);
     if (LANE < 3) com[3 * (size_t)inst + LANE] = L[P_COM + LANE];
 }
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s)
@@ -1892,7 +2007,7 @@ extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *ou
 }
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
 {
-    hipLaunchKernelGGL(lmh_rollout_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, log, n_ticks);
+    hipLaunchKernelGGL(lmh_rollout_kernel, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, log, n_ticks);
 }
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s)
 {
