@@ -1130,7 +1130,8 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
     unsigned F = *F_io & ~forced;
     double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
     qmax = wave_max(qmax);
-    const double toll = 1e-12 * (1.0 + qmax);                    // ~100x the round-off of (P c - q)
+    const double toll = 1e-14 * (1.0 + qmax);                    // ~10x the round-off of (P c - q): a looser bound lets a warm start keep a coefficient
+                                                                   // out whose multiplier is slightly negative (1e-6 relative error in tau after a contact switch)
     const bool mine = (lane < 32) && !((forced >> lane) & 1u);
     int ninf = 33, budget = 3;
     bool lh = false;                                               // false: block pivoting, true: Lawson-Hanson
@@ -1629,28 +1630,37 @@ __device__ __forceinline__ void store_out(const double *L, double *out)
 
 // ============================================================================ kernels
 // Controller::standStep + WBC for every instance (src/controller.cpp:48-154).
+// The plain kernel runs two waves per robot like the rollout; the debug kernel (intermediate dumps, stamps) keeps
+// the single-wave schedule.
 template <bool DEBUG>
-__global__ void __launch_bounds__(64) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
+__global__ void __launch_bounds__(DEBUG ? 64 : LMH_ROLLOUT_THREADS) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
 {
+    constexpr int NW = DEBUG ? 1 : 2;
     __shared__ double L[LDS_DOUBLES];
     const int inst = blockIdx.x;
     if (inst >= P.n_instances) return;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double *st = state + (size_t)LMH_STATE_STRIDE * inst;
-    load_common(L, P, inst);
-    for (int e = LANE; e < 91; e += 64) L[P_Q + e] = st[e];        // q | v | v_prev | t
-    WSYNC();
-    const double t = L[P_TIME];
-    unsigned F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
-    F = P.warm_start ? ~F : 0xFFFFFFFFu;                           // status keeps the ACTIVE mask
-    int k = 0, iters = 0;
+    const double t = st[90];
+    unsigned F = 0xFFFFFFFFu;
     SET_GDBG(DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
-    WSYNC();
-    const int flags = controller_eval<1>(L, P, inst, t, 0, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
-    store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
-    if (LANE < 30) st[60 + LANE] = L[P_V + LANE];                  // Robot::v_ <- dq (controller.cpp:59)
-    if (LANE == 0) {
-        int32_t *s = status + LMH_STATUS_STRIDE * inst;
-        s[0] = k; s[1] = iters; s[2] = flags; s[3] = (int32_t)(~F);
+    if (wid == 0) {
+        load_common(L, P, inst);
+        for (int e = LANE; e < 91; e += 64) L[P_Q + e] = st[e];    // q | v | v_prev | t
+        F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
+        F = P.warm_start ? ~F : 0xFFFFFFFFu;                       // status keeps the ACTIVE mask
+        WSYNC();
+    }
+    bsync<NW>();
+    int k = 0, iters = 0;
+    const int flags = controller_eval<NW>(L, P, inst, t, wid, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    if (wid == 0) {
+        store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
+        if (LANE < 30) st[60 + LANE] = L[P_V + LANE];              // Robot::v_ <- dq (controller.cpp:59)
+        if (LANE == 0) {
+            int32_t *s = status + LMH_STATUS_STRIDE * inst;
+            s[0] = k; s[1] = iters; s[2] = flags; s[3] = (int32_t)(~F);
+        }
     }
 }
 
@@ -2003,7 +2013,7 @@ extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *c
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s)
 {
     if (debug) hipLaunchKernelGGL(lmh_eval_kernel<true>, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
-    else hipLaunchKernelGGL(lmh_eval_kernel<false>, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
+    else hipLaunchKernelGGL(lmh_eval_kernel<false>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
 }
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
 {

@@ -108,5 +108,20 @@ def walk_plan(simulation_time, time_step, num_steps=4, time_per_step=0.5, ds_tim
     return dict(zmp_x=zx, zmp_y=zy, phase=ph, segs=np.array(segs), seg_of_sample=sos)
 
 
-__all__ = ["stance_zmp", "find_poly_coeff", "foot_coeff_trajectory", "walk_plan",
+def jump_plan(simulation_time, time_step, stance_time=0.4, flight_time=0.15):
+    """Build-defined jumping contact schedule (BASELINE config 5; the reference only hints at it: "0 reaction
+    variables" in the comment at controller.hpp:98): double support for stance_time, PHASE_FLIGHT for
+    flight_time (both feet forced out of the QP), double support afterwards.  ZMP references stay at the
+    stance values of ZMP::stanceZMP(Double); the feet keep their constant polynomials.
+    Returns dict(zmp_x, zmp_y, phase) on the ZMP::stanceZMP sample grid."""
+    zx, zy = stance_zmp(simulation_time, time_step, 2)
+    n = len(zx)
+    ph = np.full(n, PHASE_DOUBLE, dtype=np.uint8)
+    a = min(n, int(round(stance_time / time_step)))
+    b = min(n, int(round((stance_time + flight_time) / time_step)))
+    ph[a:b] = PHASE_FLIGHT
+    return dict(zmp_x=zx, zmp_y=zy, phase=ph)
+
+
+__all__ = ["stance_zmp", "find_poly_coeff", "foot_coeff_trajectory", "walk_plan", "jump_plan",
            "PHASE_DOUBLE", "PHASE_RIGHT", "PHASE_LEFT", "PHASE_FLIGHT"]

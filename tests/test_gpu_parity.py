@@ -318,6 +318,161 @@ def test_walking_contact_switching_parity(cfg2):
     assert saw_single_support
 
 
+def test_jump_schedule_parity_config5_ingredients(cfg2):
+    """BASELINE config-5 ingredients at small scale: N = 48, double support -> flight -> double support.
+    Rollout across both contact switches against the oracle; k bit-exact, contact wrenches exactly zero in
+    flight, tau / f within 1e-6."""
+    from linearmpchumanoid_amd import trajectories
+    from oracle.pyoracle import Oracle
+    dt, N = 1e-3, 48
+    th = N * dt
+    plan = trajectories.jump_plan(0.5, dt, stance_time=0.03, flight_time=0.04)
+    nt = 110                                                       # 30 ticks stance, 40 flight, 40 stance again
+    B = 4
+    v = perturbed_velocities(B, seed=61) * 0.2
+    ctl = make_controller(B, dt, th, cfg2["zcom"], warm_start=1)
+    ctl.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+    st = ctl.new_state(cfg2["q0"], v, t=0.0)
+    out, status, log = ctl.rollout(st, nt, log=True)
+    torch.cuda.synchronize()
+    stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
+    assert (status[:, 2] == 0).all()
+    flight_ticks = 0
+    for i in range(B):
+        o = Oracle(sim_time=0.5, dt=dt, horizon_time=th, do_ik=True)
+        o.set_zcom(cfg2["zcom"])
+        o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+        r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, nt, log=True)
+        assert status[i, 0] == r["k"][-1]
+        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+        for tk in range(nt):
+            ref = r["log"][tk]
+            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
+            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+            if plan["phase"][r["k"][tk]] == 3:                      # k of the logged (stage-4) evaluation
+                flight_ticks += 1
+                assert np.abs(log[tk, i, 24:]).max() == 0.0        # no contact force at all, exactly
+                assert np.abs(ref[24:]).max() < 1e-9
+    assert flight_ticks >= B * 30
+
+
+def _walk_setup(ctl, plan, xs):
+    ctl.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+    ctl.set_segments(plan["segs"], plan["seg_of_sample"])
+    ctl.set_xscale(xs)
+
+
+def test_full_size_walking_config3(cfg2):
+    """BASELINE configs[2] at full size: 4096 instances, N = 32, walking with contact switching and a
+    per-instance step length U(0.02, 0.05) (seed 20260003 + i).  Size-independent properties for every
+    instance (no flags, swing foot carries exactly no force, contact forces inside the friction cone, k
+    bit-exact against the float-accumulated clock, instance order irrelevant) + every 512th instance against
+    its own oracle rollout."""
+    from linearmpchumanoid_amd import trajectories
+    from oracle.pyoracle import Oracle
+    dt, N, B, nt = 1e-3, 32, 4096, 460
+    th = N * dt
+    plan = trajectories.walk_plan(1.0, dt, num_steps=2, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.1)
+    xs = np.array([np.random.default_rng(20260003 + i).uniform(0.02, 0.05) for i in range(B)])
+    ctl = make_controller(B, dt, th, cfg2["zcom"], warm_start=1)
+    _walk_setup(ctl, plan, xs)
+    st = ctl.new_state(cfg2["q0"], np.zeros(30), t=0.0)
+    out, status, log = ctl.rollout(st, nt, log=True)
+    torch.cuda.synchronize()
+    stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
+    assert (status[:, 2] == 0).all()
+    # k of the last evaluation (stage 4 of the last tick): int((t + dt)/dt) on the float-accumulated clock
+    t = 0.0
+    for _ in range(nt - 1):
+        t += dt
+    assert (status[:, 0] == int((t + dt) / dt)).all()
+    # support phase per tick from the same k sequence (stage-4 evaluation is what the log holds)
+    t = 0.0
+    mu = 0.7
+    seen = set()
+    for tk in range(nt):
+        ph = int(plan["phase"][int((t + dt) / dt)])
+        seen.add(ph)
+        f = log[tk, :, 24:36]
+        if ph == 1:
+            assert np.abs(f[:, 6:]).max() == 0.0                   # right support: the left (swing) foot carries nothing
+        if ph == 2:
+            assert np.abs(f[:, :6]).max() == 0.0
+        for ft in range(2):
+            fx, fy, fz = f[:, 6 * ft + 3], f[:, 6 * ft + 4], f[:, 6 * ft + 5]
+            assert (fz > -1e-7).all() and (np.abs(fx) <= mu * fz + 1e-7).all() and (np.abs(fy) <= mu * fz + 1e-7).all()
+        t += dt
+    assert seen == {0, 1, 2}
+    # instance order does not matter (bit for bit)
+    ctl2 = make_controller(B, dt, th, cfg2["zcom"], warm_start=1)
+    _walk_setup(ctl2, plan, xs[::-1].copy())
+    st2 = ctl2.new_state(cfg2["q0"], np.zeros(30), t=0.0)
+    out2, _, _ = ctl2.rollout(st2, nt)
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy()[::-1], out.cpu().numpy())
+    for i in range(0, B, 512):
+        o = Oracle(sim_time=1.0, dt=dt, horizon_time=th, do_ik=True)
+        o.set_zcom(cfg2["zcom"])
+        o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+        o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
+        r = o.rollout(np.concatenate([cfg2["q0"], np.zeros(30)]), 0.0, nt, log=True)
+        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+        for tk in range(0, nt, 5):
+            ref = r["log"][tk]
+            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
+            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+
+
+def test_randomised_walking_config4_ingredients(cfg2):
+    """BASELINE configs[3] on one GPU's share at small scale: per-link mass x U(0.9,1.1) and CoM +- 5 mm
+    (seed 20260004 + i), per-instance start posture from the IK KERNEL on the randomised model, per-instance
+    LIPM height = that posture's CoM height, then walking.  Each instance against an oracle built from the
+    same raw link table (which runs its own IK)."""
+    from linearmpchumanoid_amd import trajectories
+    from linearmpchumanoid_amd.controller import nominal_links, initial_configuration
+    from oracle.pyoracle import Oracle
+    dt, N, B, nt = 1e-3, 32, 6, 160
+    th = N * dt
+    raw = np.tile(nominal_links(), (B, 1, 1))
+    for i in range(B):
+        rng = np.random.default_rng(20260004 + i)
+        raw[i, :, 0] *= rng.uniform(0.9, 1.1, 28)
+        raw[i, :, 1:4] += rng.uniform(-5e-3, 5e-3, (28, 3)) * (raw[i, :, 0:1] > 0)
+    plan = trajectories.walk_plan(1.0, dt, num_steps=2, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.05)
+    xs = np.linspace(0.02, 0.05, B)
+    ctl = make_controller(B, dt, th, cfg2["zcom"], warm_start=1)
+    ctl.set_model(raw)
+    q = torch.as_tensor(np.tile(initial_configuration(), (B, 1))).to(ctl.device)
+    q, iters = ctl.ik(q)                                           # Kinematics::compute per instance, randomised model
+    com = torch.zeros((B, 3), dtype=torch.float64, device=ctl.device)
+    from linearmpchumanoid_amd import capi
+    import ctypes as C
+    capi.check(capi.lib().lmh_robot_com(ctl._h, C.c_void_p(q.data_ptr()), C.c_void_p(com.data_ptr()), ctl._stream()))
+    torch.cuda.synchronize()
+    q0s, zc = q.cpu().numpy(), com.cpu().numpy()[:, 2].copy()
+    assert (iters.cpu().numpy() <= 6).all()
+    assert np.abs(com.cpu().numpy() - np.array([-0.02, 0.0, 0.26])).max() < 1e-9    # the IK target
+    ctl.set_zcom(zc)
+    _walk_setup(ctl, plan, xs)
+    st = ctl.new_state(q0s, np.zeros(30), t=0.0)
+    out, status, log = ctl.rollout(st, nt, log=True)
+    torch.cuda.synchronize()
+    stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
+    assert (status[:, 2] == 0).all()
+    for i in range(B):
+        o = Oracle(sim_time=1.0, dt=dt, horizon_time=th, do_ik=True, raw_links=raw[i])
+        assert np.abs(o.robot()["q"] - q0s[i]).max() < 1e-10       # same IK posture
+        assert abs(o.zcom - zc[i]) < 1e-12
+        o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+        o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
+        r = o.rollout(np.concatenate([o.robot()["q"], np.zeros(30)]), 0.0, nt, log=True)
+        assert status[i, 0] == r["k"][-1]
+        for tk in range(0, nt, 3):
+            ref = r["log"][tk]
+            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
+            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+
+
 # ------------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("N", [48, 64])
 def test_long_horizons(cfg2, N):
