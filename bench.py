@@ -25,6 +25,7 @@ ALG_BYTES_PER_TICK = 1248        # state in (60 f64) + state out (60)
 ALG_FLOP_PER_TICK = 8.0e5        # 2.0e5 flop per controller evaluation x 4
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP64_VALU_PEAK_TFLOPS = 78.6     # vendor fp64 vector peak
+PROFILE_TAG = "r01b"             # profiles/<tag>_rollout_summary.json: PMC passes of the kernel as committed
 
 
 def parse():
@@ -91,13 +92,14 @@ def cpu_baseline(q0, zcom, args):
 
 def profiled_traffic(args):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, profiles/r01_rollout_summary.json); only valid for the workload it was collected on."""
+    WRITE_SIZE, profiles/<PROFILE_TAG>_rollout_summary.json, made by scripts/profile_rollout.sh +
+    scripts/summarise_profile.py); only valid for the workload it was collected on."""
     if args.traffic is not None:
         return args.traffic
     if (args.instances, args.ticks, args.horizon) != (1024, 10, 16) or args.cold:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_rollout_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_rollout_summary.json")) as f:
             d = json.load(f)["derived"]
         return d["hbm_write_bytes_per_launch"] + d["hbm_fetch_bytes_per_launch_x2_gfx950_correction"]
     except Exception:
