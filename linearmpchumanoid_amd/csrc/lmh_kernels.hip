@@ -189,17 +189,31 @@ __device__ __forceinline__ double x_force(const double *E, const double *Bm, con
     const double t2 = Bm[a] * f[3] + Bm[3 + a] * f[4] + Bm[6 + a] * f[5];
     return up ? t1 + t2 : t1;
 }
+// Lane exchange inside a 16-lane row through DPP (two 32-bit v_mov_dpp per double, ~10 cycles) instead of
+// ds_bpermute (an LDS round trip per step).  CTRL: 0xB1 = quad_perm[1,0,3,2] (lane ^ 1), 0x4E = quad_perm[2,3,0,1]
+// (lane ^ 2), 0x141 = row_half_mirror, 0x140 = row_mirror.  Needs a full exec mask (wave-uniform control flow).
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane_f64(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// all-reduce over the 64 lanes: four DPP steps leave every lane with its row's total, the four row totals are
+// combined through SGPRs in a fixed order (wave-uniform result)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v); v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
+    return (read_lane_f64(v, 0) + read_lane_f64(v, 16)) + (read_lane_f64(v, 32) + read_lane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, dpp_row<0xB1>(v)); v = fmax(v, dpp_row<0x4E>(v)); v = fmax(v, dpp_row<0x141>(v)); v = fmax(v, dpp_row<0x140>(v));
+    return fmax(fmax(read_lane_f64(v, 0), read_lane_f64(v, 16)), fmax(read_lane_f64(v, 32), read_lane_f64(v, 48)));
 }
 
 __device__ __forceinline__ double fast_rcp(double d)
@@ -693,7 +707,7 @@ __device__ __forceinline__ void phase_crba(double *L)
         body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, r, cb, leaf);
         if (dl == nact) { ic[0] = leaf[0]; ic[1] = leaf[1]; ic[2] = leaf[2]; }   // leaf: Ic = I (Dynamics.cpp:72)
         if (on && cb == 0) L[A_FB + 6 * (f_act(i) - 1) + r] = ic[2];             // f = Ic_i S for the joint columns
-        const double p0 = __shfl_xor(ic[0], 1, 64), p1 = __shfl_xor(ic[1], 1, 64), p2 = __shfl_xor(ic[2], 1, 64);
+        const double p0 = dpp_row<0xB1>(ic[0]), p1 = dpp_row<0xB1>(ic[1]), p2 = dpp_row<0xB1>(ic[2]);   // partner lane ^ 1 (cb ^ 1)
         const double lo[3] = {cb ? p0 : ic[0], cb ? p1 : ic[1], cb ? p2 : ic[2]};
         const double hi[3] = {cb ? ic[0] : p0, cb ? ic[1] : p1, cb ? ic[2] : p2};
         WSYNC();                                                   // A_YT of the previous level has been consumed
