@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
+    ap.add_argument("--summary-out", default=None, help="write the gathered end-of-run summary (wire.write_summary format) to this path")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from rocprofv3 --pmc; default: the committed profiles/ summary when the workload matches it")
     return ap.parse_args()
@@ -166,6 +167,9 @@ def main():
         summary = summary.cpu()
     gathered = sharding.gather_summaries(summary, world, rank)
     flags = int((status[:, 2] != 0).sum().item())
+    if rank == 0 and args.summary_out and gathered is not None:
+        from linearmpchumanoid_amd import wire
+        wire.write_summary(args.summary_out, gathered.cpu().numpy(), dt=args.dt)
 
     if rank == 0:
         total_instances = B * world

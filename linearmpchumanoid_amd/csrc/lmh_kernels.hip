@@ -1125,7 +1125,11 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_o
 #pragma unroll
         for (int bq = 0; bq < 16; bq++) s += Pr[bq] * cc[bq];
     }
-    s += __shfl_xor(s, 32, 64);
+    {   // s[l] + s[l ^ 32] in every lane: gfx950 v_permlane32_swap (no LDS round trip)
+        const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(s), __double2loint(s), false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(s), __double2hiint(s), false, false);
+        s = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+    }
     *z_out = inF ? zj : 0.0;
     *lam_out = (lane < 32 && !((F >> lane) & 1u)) ? s - L[P_QV + r] : 0.0;
     return bad;
