@@ -56,6 +56,10 @@ extern "C" {
 #define LMH_PHASE_LEFT 2
 #define LMH_PHASE_FLIGHT 3
 
+/* arithmetic of the model-term phases (BASELINE config 5 tolerance sweep; build-defined, the reference is fp64 only) */
+#define LMH_PRECISION_FP64 0
+#define LMH_PRECISION_MIXED 1
+
 enum {
     LMH_OK = 0,
     LMH_ERR_NO_DEVICE = -1,
@@ -78,6 +82,9 @@ typedef struct lmh_config {
     double eps_coeff;
     int32_t warm_start;    /* 1: start the active set from the previous evaluation's (same minimiser) */
     int32_t max_qp_iters;
+    int32_t precision;     /* LMH_PRECISION_FP64 (reference arithmetic) | LMH_PRECISION_MIXED: model terms (kinematics, C, M, J) in
+                              fp32 arithmetic, references + QP in fp64; k = int(t/dt) is computed in fp64 in every mode */
+    int32_t reserved;
 } lmh_config;
 
 typedef struct lmh_handle lmh_handle;

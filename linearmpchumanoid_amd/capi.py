@@ -22,6 +22,7 @@ FLAG_ZMP_RANGE = 4
 FLAG_NOT_SPD = 8
 
 PHASE_DOUBLE, PHASE_RIGHT, PHASE_LEFT, PHASE_FLIGHT = 0, 1, 2, 3
+PRECISION_FP64, PRECISION_MIXED = 0, 1   # lmh_config.precision (include/lmh.h)
 
 # every symbol include/lmh.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -39,7 +40,7 @@ class LmhConfig(C.Structure):
         "dt", "time_horizon", "z_com", "gravity", "alpha", "beta", "mu",
         "kp_joints", "kd_joints", "kp_mom", "kd_mom", "kp_feet", "kd_feet",
         "w_com_lin", "w_com_ang", "w_base_pos", "w_base_ang", "w_joints", "w_force", "w_foot",
-        "eps_coeff")] + [("warm_start", C.c_int32), ("max_qp_iters", C.c_int32)]
+        "eps_coeff")] + [("warm_start", C.c_int32), ("max_qp_iters", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

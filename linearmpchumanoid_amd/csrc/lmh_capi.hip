@@ -60,7 +60,7 @@ extern "C" void lmh_config_default(lmh_config *c)
     c->w_com_lin = 4000; c->w_com_ang = 0; c->w_base_pos = 10; c->w_base_ang = 10;   // :118-121
     c->w_joints = 1; c->w_force = 1; c->w_foot = 100000;            // :122-124
     c->eps_coeff = 1e-8;                                            // controller.cpp:117
-    c->warm_start = 1; c->max_qp_iters = 64;
+    c->warm_start = 1; c->max_qp_iters = 64; c->precision = LMH_PRECISION_FP64;
 }
 
 extern "C" void lmh_nominal_links(double *raw) { std::memcpy(raw, kLmhNaoLinks, sizeof(kLmhNaoLinks)); }
@@ -218,7 +218,7 @@ static void fill_params(lmh_handle *h)
     P.mpc_stride = 3 * (h->N + 1) + 4;
     P.mpc_stride_inst = (h->n_gain > 1) ? P.mpc_stride : 0;
     P.n_samples = h->n_samples; P.horizon = h->N; P.n_instances = h->B;
-    P.warm_start = c.warm_start; P.max_qp_iters = c.max_qp_iters;
+    P.warm_start = c.warm_start; P.max_qp_iters = c.max_qp_iters; P.precision = c.precision;
     P.dt = c.dt;
     P.kp_joints = c.kp_joints; P.kd_joints = c.kd_joints; P.kp_mom = c.kp_mom; P.kd_mom = c.kd_mom;
     P.kp_feet = c.kp_feet; P.kd_feet = c.kd_feet;
@@ -253,6 +253,7 @@ extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lm
     h->cfg = *cfg; h->B = n_instances; h->device = device;
     h->N = (int)(cfg->time_horizon / cfg->dt);                      // mpcLinearPendulum.cpp:43
     if (h->N < 1 || h->N > LMH_MAX_HORIZON) { delete h; return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/dt must be in [1, 64]"); }
+    if (cfg->precision != LMH_PRECISION_FP64 && cfg->precision != LMH_PRECISION_MIXED) { delete h; return fail(LMH_ERR_BAD_ARG, "precision must be LMH_PRECISION_FP64 or LMH_PRECISION_MIXED"); }
     std::memset(&h->P, 0, sizeof(h->P));
     double g[16 * 6 + 36 + 96 + 3 * 336];
     build_gcol(cfg->mu, g);

@@ -27,6 +27,7 @@ struct LmhDevParams {
     int32_t n_instances;
     int32_t warm_start;
     int32_t max_qp_iters;
+    int32_t precision;          // 0: fp64 throughout; 1: mixed (fp32 model terms, fp64 references + QP)
     // ---- scalars (reference literals, see include/lmh.h lmh_config)
     double dt;
     double kp_joints, kd_joints, kp_mom, kd_mom, kp_feet, kd_feet;

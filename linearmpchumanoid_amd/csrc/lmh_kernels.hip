@@ -168,25 +168,48 @@ __shared__ double *g_dbg;
 #define SET_GDBG(p) do { } while (0)
 #endif
 
+// ---- LDS views with a working precision R.  The model-term phases (kinematics, Newton-Euler, CRBA, Jacobian) are
+// written against LV<R>: element loads convert the stored fp64 value to R, stores convert back, so R = double is
+// the plain fp64 path and R = float runs those phases in fp32 arithmetic ("mixed" precision: fp32 model terms,
+// fp64 references and QP) without a second LDS layout.
+template <typename R>
+struct LRef {
+    double *p;
+    __device__ __forceinline__ operator R() const { return (R)*p; }
+    __device__ __forceinline__ LRef &operator=(R v) { *p = (double)v; return *this; }
+    __device__ __forceinline__ LRef &operator=(const LRef &o) { *p = (double)(R)*o.p; return *this; }
+    __device__ __forceinline__ LRef &operator+=(R v) { *p = (double)((R)*p + v); return *this; }
+};
+template <typename R>
+struct LV {
+    double *p;
+    __device__ __forceinline__ LV(double *q) : p(q) {}
+    __device__ __forceinline__ LV(const double *q) : p(const_cast<double *>(q)) {}   // read-only use (tables in HBM / L2)
+    __device__ __forceinline__ LV operator+(int o) const { return LV(p + o); }
+    __device__ __forceinline__ LRef<R> operator[](int i) const { return LRef<R>{p + i}; }
+};
+
 // (X m)[k] for X = [E' 0; B E'],  m = [ang; lin]   (generalizedFunctions.cpp:11-19); branch-free
-__device__ __forceinline__ double x_mot(const double *E, const double *Bm, const double *m, int k)
+template <typename R, typename MV>
+__device__ __forceinline__ R x_mot(const LV<R> E, const LV<R> Bm, const MV &m, int k)
 {
     const bool up = k < 3;
     const int a = up ? k : k - 3;
-    const double *p = up ? E + a : Bm + 3 * a;
+    const LV<R> p = up ? E + a : Bm + 3 * a;
     const int st = up ? 3 : 1;
-    const double t1 = p[0] * m[0] + p[st] * m[1] + p[2 * st] * m[2];
-    const double t2 = E[a] * m[3] + E[3 + a] * m[4] + E[6 + a] * m[5];
+    const R t1 = p[0] * m[0] + p[st] * m[1] + p[2 * st] * m[2];
+    const R t2 = E[a] * m[3] + E[3 + a] * m[4] + E[6 + a] * m[5];
     return up ? t1 : t1 + t2;
 }
 // (X' f)[k],  X' = [E B'; 0 E]; branch-free
-__device__ __forceinline__ double x_force(const double *E, const double *Bm, const double *f, int k)
+template <typename R>
+__device__ __forceinline__ R x_force(const LV<R> E, const LV<R> Bm, const LV<R> f, int k)
 {
     const bool up = k < 3;
     const int a = up ? k : k - 3;
-    const double *g = up ? f : f + 3;
-    const double t1 = E[a * 3] * g[0] + E[a * 3 + 1] * g[1] + E[a * 3 + 2] * g[2];
-    const double t2 = Bm[a] * f[3] + Bm[3 + a] * f[4] + Bm[6 + a] * f[5];
+    const LV<R> g = up ? f : f + 3;
+    const R t1 = E[a * 3] * g[0] + E[a * 3 + 1] * g[1] + E[a * 3 + 2] * g[2];
+    const R t2 = Bm[a] * f[3] + Bm[3 + a] * f[4] + Bm[6 + a] * f[5];
     return up ? t1 + t2 : t1;
 }
 // Lane exchange inside a 16-lane row through DPP (two 32-bit v_mov_dpp per double, ~10 cycles) instead of
@@ -199,6 +222,11 @@ __device__ __forceinline__ double dpp_row(double x)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ double read_lane_f64(double x, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
@@ -209,6 +237,12 @@ __device__ __forceinline__ double wave_sum(double v)
 {
     v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v); v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
     return (read_lane_f64(v, 0) + read_lane_f64(v, 16)) + (read_lane_f64(v, 32) + read_lane_f64(v, 48));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v); v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)))
+         + (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
 }
 __device__ __forceinline__ double wave_max(double v)
 {
@@ -400,25 +434,29 @@ __device__ __forceinline__ v4d mfma_tile(FA a_of, FB b_of)
     return acc;
 }
 
+__device__ __forceinline__ void sincos_r(double x, double *s, double *c) { sincos(x, s, c); }
+__device__ __forceinline__ void sincos_r(float x, float *s, float *c) { sincosf(x, s, c); }
+
 // ============================================================================ kinematics
 // Robot::forwardKinematics + matTrans + eulerAnglesToSO3 (Robot.cpp:45-160,176-223,
 // generalizedFunctions.cpp:52-72).  Reads L[P_Q], writes A_T (30 x 3x4) and L[P_SC].
-__device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
+template <typename R>
+__device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
 {
     const int lane = LANE;
     // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos
-    double c0[6], c1[6], c2[6];
+    R c0[6], c1[6], c2[6];
 #pragma unroll
     for (int u = 0; u < 6; u++) {
         const int e = lane + 64 * u;
-        const double *cf = lcoef + 3 * ((e < 336) ? e : 0);
+        const LV<R> cf = lcoef + 3 * ((e < 336) ? e : 0);
         c0[u] = cf[0]; c1[u] = cf[1]; c2[u] = cf[2];
     }
     if (lane < 28) {
-        double s, c;
-        if (lane < 24) sincos(L[P_Q + 6 + lane] + L[P_TAB + lane], &s, &c);
+        R s, c;
+        if (lane < 24) sincos_r((R)L[P_Q + 6 + lane] + (R)L[P_TAB + lane], &s, &c);
         else if (lane == 24) { s = -1.0; c = CPI2; }              // theta[24] = -pi/2 (Robot.cpp:87)
-        else sincos(L[P_Q + 3 + (lane - 25)], &s, &c);            // roll, pitch, yaw
+        else sincos_r((R)L[P_Q + 3 + (lane - 25)], &s, &c);            // roll, pitch, yaw
         L[P_SC + 2 * lane] = s;
         L[P_SC + 2 * lane + 1] = c;
     }
@@ -440,8 +478,8 @@ __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
     }
     if (lane < 12) {                                               // T0 = [R(rpy) p]
         const int r = lane >> 2, col = lane & 3;
-        const double sr = L[P_SC + 50], cr = L[P_SC + 51], sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
-        double val;
+        const R sr = L[P_SC + 50], cr = L[P_SC + 51], sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
+        R val;
         if (col == 3) val = L[P_Q + r];
         else if (r == 0) val = (col == 0) ? cy * cp : (col == 1) ? cy * sp * sr - sy * cr : cy * sp * cr + sy * sr;
         else if (r == 1) val = (col == 0) ? sy * cp : (col == 1) ? sy * sp * sr + cy * cr : sy * sp * cr - cy * sr;
@@ -456,9 +494,9 @@ __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
         int dst, src, loc;
         fk_sched(c, s, &dst, &src, &loc);
         const bool on = (lane < 60) && (dst >= 0);
-        const double *Ts = L + A_T + 12 * (on ? src : 0) + 4 * r;
-        const double *Lo = L + A_LC + 12 * (on ? loc : 0) + col;
-        double val = Ts[0] * Lo[0] + Ts[1] * Lo[4] + Ts[2] * Lo[8];
+        const LV<R> Ts = L + A_T + 12 * (on ? src : 0) + 4 * r;
+        const LV<R> Lo = L + A_LC + 12 * (on ? loc : 0) + col;
+        R val = Ts[0] * Lo[0] + Ts[1] * Lo[4] + Ts[2] * Lo[8];
         val += (col == 3) ? Ts[3] : 0.0;
         if (on) L[A_T + 12 * dst + el] = val;
     }
@@ -469,15 +507,15 @@ __device__ __forceinline__ void phase_fk(double *L, const double *lcoef)
 // (Robot.cpp:276-298, generalizedFunctions.cpp:11-27: R' used as inverse, kept).
 // NW = 2: wave 0 owns the CoM, frames 0..13 and the persistent copies, wave 1 frames 14..27 (B of a frame needs
 // only that frame's E, p, so the two halves never wait for each other; the caller joins them).
-template <int NW>
-__device__ __forceinline__ void phase_com_x(double *L, int wid)
+template <int NW, typename R>
+__device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
 {
     const int lane = LANE;
     if (wid == 0) {
-        double cx = 0, cy = 0, cz = 0;
+        R cx = 0, cy = 0, cz = 0;
         if (lane < 28) {
-            const double *T = L + A_T + 12 * lane, *mo = L + P_MODEL + LMH_BODY_STRIDE * lane;
-            const double m = mo[12];
+            const LV<R> T = L + A_T + 12 * lane, mo = L + P_MODEL + LMH_BODY_STRIDE * lane;
+            const R m = mo[12];
             if (m != 0.0) {
                 // joint-frame com = (m c)/m is not stored; the model keeps m*c, so use it directly
                 cx = T[0] * mo[9] + T[1] * mo[10] + T[2] * mo[11] + m * T[3];
@@ -487,7 +525,7 @@ __device__ __forceinline__ void phase_com_x(double *L, int wid)
         }
         cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
         if (lane == 0) {
-            const double mass = L[P_MODEL + 392];
+            const R mass = L[P_MODEL + 392];
             L[P_COM] = cx / mass; L[P_COM + 1] = cy / mass; L[P_COM + 2] = cz / mass;
         }
     }
@@ -498,14 +536,14 @@ __device__ __forceinline__ void phase_com_x(double *L, int wid)
         const int i = f_lo + e / 12, el = e % 12;
         const bool isE = el < 9;
         const int a = isE ? el / 3 : el - 9, col = isE ? el % 3 : 3;
-        const double *Ti = L + A_T + 12 * i + col, *Tp = L + A_T + 12 * f_parent(i);
-        const double t0 = Tp[a], t1 = Tp[4 + a], t2 = Tp[8 + a];
-        const double s1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
-        const double s2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
+        const LV<R> Ti = L + A_T + 12 * i + col, Tp = L + A_T + 12 * f_parent(i);
+        const R t0 = Tp[a], t1 = Tp[4 + a], t2 = Tp[8 + a];
+        const R s1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
+        const R s2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
         L[(isE ? A_XE + 9 * i + el : A_XP + 3 * i + (el - 9))] = isE ? s1 : s1 + s2;
     }
     if (wid == 0 && lane < 12) {                                   // frame 0: E = R0, p = p0
-        const double *T0 = L + A_T;
+        const LV<R> T0 = L + A_T;
         if (lane < 9) L[A_XE + lane] = T0[(lane / 3) * 4 + lane % 3];
         else L[A_XP + (lane - 9)] = T0[(lane - 9) * 4 + 3];
     }
@@ -514,8 +552,8 @@ __device__ __forceinline__ void phase_com_x(double *L, int wid)
     const int b_lo = (NW == 2 && wid == 1) ? 14 : 0, b_n = (NW == 1) ? 28 : 14;
     for (int e = lane; e < b_n * 9; e += 64) {
         const int i = b_lo + e / 9, a = (e % 9) / 3, b = e % 3;
-        const double *E = L + A_XE + 9 * i, *p = L + A_XP + 3 * i;
-        double val;                                               // B = (-E') [p]x
+        const LV<R> E = L + A_XE + 9 * i, p = L + A_XP + 3 * i;
+        R val;                                               // B = (-E') [p]x
         if (b == 0) val = (-E[3 + a]) * p[2] + E[6 + a] * p[1];
         else if (b == 1) val = E[a] * p[2] + (-E[6 + a]) * p[0];
         else val = (-E[a]) * p[1] + E[3 + a] * p[0];
@@ -530,11 +568,11 @@ __device__ __forceinline__ void phase_com_x(double *L, int wid)
         // base-frame reordered velocities, stale (Robot::v_) and fresh: swapBaseVelocityAndRefToWorldFrame
         if (lane < 60) {
             const int which = lane / 30, i = lane % 30;
-            const double *v = L + (which ? P_V : P_VP);
-            double val;
+            const LV<R> v = L + (which ? P_V : P_VP);
+            R val;
             if (i < 6) {
-                const double m[6] = {v[3], v[4], v[5], v[0], v[1], v[2]};
-                val = x_mot(L + A_XE, L + A_XB, m, i);
+                const R m[6] = {v[3], v[4], v[5], v[0], v[1], v[2]};
+                val = x_mot<R>(L + A_XE, L + A_XB, m, i);
             } else val = v[i];
             L[(which ? P_VHN : P_VHS) + i] = val;
         }
@@ -544,14 +582,15 @@ __device__ __forceinline__ void phase_com_x(double *L, int wid)
 
 // Dynamics::computeC (gravity / no gravity) + computeJpqpFrame(7),(14): forward and backward
 // Newton-Euler with qdd = 0 on the STALE velocity (Dynamics.cpp:29-60,124-200).
-__device__ __forceinline__ void phase_newton_euler(double *L)
+template <typename R>
+__device__ __forceinline__ void phase_newton_euler(LV<R> L)
 {
     const int lane = LANE;
     // base: vel0 = vhat[0:6]; accg0 = X0 * [0 0 0 0 0 9.81]; acc00 = 0
     if (lane < 6) {
         L[A_VEL + lane] = L[P_VHS + lane];
-        const double g[6] = {0, 0, 0, 0, 0, 9.81};
-        L[A_ACCG + lane] = x_mot(L + A_XE, L + A_XB, g, lane);
+        const R g[6] = {0, 0, 0, 0, 0, 9.81};
+        L[A_ACCG + lane] = x_mot<R>(L + A_XE, L + A_XB, g, lane);
         L[A_ACC0 + lane] = 0.0;
     }
     {   // velocity and acceleration sweeps, software-pipelined by one level: step d computes vel at chain depth d
@@ -570,18 +609,18 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
             // ---- velocity, depth index d
             const int iv = base + ((d < nact) ? d : 0);
             const int pv = (d == 0) ? 0 : iv - 1;
-            double vval = x_mot(L + A_XE + 9 * iv, L + A_XB + 9 * iv, L + A_VEL + 6 * pv, k);
-            const double qdv = L[P_VHS + 5 + iv - adj];
+            R vval = x_mot<R>(L + A_XE + 9 * iv, L + A_XB + 9 * iv, L + A_VEL + 6 * pv, k);
+            const R qdv = L[P_VHS + 5 + iv - adj];
             vval += (k == 2) ? qdv : 0.0;
             // ---- acceleration, depth index d-1
             const int e = d - 1;
             const int ia = base + ((e >= 0 && e < nacc) ? e : 0);
             const int pa = (e <= 0) ? 0 : ia - 1;
-            double aval = x_mot(L + A_XE + 9 * ia, L + A_XB + 9 * ia, L + abase + 6 * pa, k);
-            const double *vi = L + A_VEL + 6 * ia;
-            const double qda = L[P_VHS + 5 + ia - adj];
+            R aval = x_mot<R>(L + A_XE + 9 * ia, L + A_XB + 9 * ia, L + abase + 6 * pa, k);
+            const LV<R> vi = L + A_VEL + 6 * ia;
+            const R qda = L[P_VHS + 5 + ia - adj];
             // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
-            const double cs = (k == 0) ? vi[1] : (k == 1) ? -vi[0] : (k == 3) ? vi[4] : (k == 4) ? -vi[3] : 0.0;
+            const R cs = (k == 0) ? vi[1] : (k == 1) ? -vi[0] : (k == 3) ? vi[4] : (k == 4) ? -vi[3] : 0.0;
             aval += (e < nact) ? cs * qda : 0.0;
             if (live && which == 0 && d < nact) L[A_VEL + 6 * iv + k] = vval;
             if (live && e >= 0 && e < nacc) L[abase + 6 * ia + k] = aval;
@@ -593,23 +632,23 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
     {
         const bool fon = lane < 50;
         const int which = fon ? lane / 25 : 0, i = f_body(lane % 25);
-        const double *mo = L + P_MODEL + LMH_BODY_STRIDE * i;
-        const double *v = L + A_VEL + 6 * i, *a = L + (which ? A_ACC0 : A_ACCG) + 6 * i;
-        const double m = mo[12], hx = mo[9], hy = mo[10], hz = mo[11];
+        const LV<R> mo = L + P_MODEL + LMH_BODY_STRIDE * i;
+        const LV<R> v = L + A_VEL + 6 * i, a = L + (which ? A_ACC0 : A_ACCG) + 6 * i;
+        const R m = mo[12], hx = mo[9], hy = mo[10], hz = mo[11];
         // I a
-        double n0 = mo[0] * a[0] + mo[1] * a[1] + mo[2] * a[2] + (hy * a[5] - hz * a[4]);
-        double n1 = mo[3] * a[0] + mo[4] * a[1] + mo[5] * a[2] + (hz * a[3] - hx * a[5]);
-        double n2 = mo[6] * a[0] + mo[7] * a[1] + mo[8] * a[2] + (hx * a[4] - hy * a[3]);
-        double f0 = m * a[3] - (hy * a[2] - hz * a[1]);
-        double f1 = m * a[4] - (hz * a[0] - hx * a[2]);
-        double f2 = m * a[5] - (hx * a[1] - hy * a[0]);
+        R n0 = mo[0] * a[0] + mo[1] * a[1] + mo[2] * a[2] + (hy * a[5] - hz * a[4]);
+        R n1 = mo[3] * a[0] + mo[4] * a[1] + mo[5] * a[2] + (hz * a[3] - hx * a[5]);
+        R n2 = mo[6] * a[0] + mo[7] * a[1] + mo[8] * a[2] + (hx * a[4] - hy * a[3]);
+        R f0 = m * a[3] - (hy * a[2] - hz * a[1]);
+        R f1 = m * a[4] - (hz * a[0] - hx * a[2]);
+        R f2 = m * a[5] - (hx * a[1] - hy * a[0]);
         // I v
-        const double p0 = mo[0] * v[0] + mo[1] * v[1] + mo[2] * v[2] + (hy * v[5] - hz * v[4]);
-        const double p1 = mo[3] * v[0] + mo[4] * v[1] + mo[5] * v[2] + (hz * v[3] - hx * v[5]);
-        const double p2 = mo[6] * v[0] + mo[7] * v[1] + mo[8] * v[2] + (hx * v[4] - hy * v[3]);
-        const double l0 = m * v[3] - (hy * v[2] - hz * v[1]);
-        const double l1 = m * v[4] - (hz * v[0] - hx * v[2]);
-        const double l2 = m * v[5] - (hx * v[1] - hy * v[0]);
+        const R p0 = mo[0] * v[0] + mo[1] * v[1] + mo[2] * v[2] + (hy * v[5] - hz * v[4]);
+        const R p1 = mo[3] * v[0] + mo[4] * v[1] + mo[5] * v[2] + (hz * v[3] - hx * v[5]);
+        const R p2 = mo[6] * v[0] + mo[7] * v[1] + mo[8] * v[2] + (hx * v[4] - hy * v[3]);
+        const R l0 = m * v[3] - (hy * v[2] - hz * v[1]);
+        const R l1 = m * v[4] - (hz * v[0] - hx * v[2]);
+        const R l2 = m * v[5] - (hx * v[1] - hy * v[0]);
         // v x* (p; l) = (w x p + vl x l ; w x l)
         n0 += (v[1] * p2 - v[2] * p1) + (v[4] * l2 - v[5] * l1);
         n1 += (v[2] * p0 - v[0] * p2) + (v[5] * l0 - v[3] * l2);
@@ -617,7 +656,7 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
         f0 += (v[1] * l2 - v[2] * l1);
         f1 += (v[2] * l0 - v[0] * l2);
         f2 += (v[0] * l1 - v[1] * l0);
-        double *fo = L + (which ? A_F0 : A_FG) + 6 * i;
+        LV<R> fo = L + (which ? A_F0 : A_FG) + 6 * i;
         if (fon) { fo[0] = n0; fo[1] = n1; fo[2] = n2; fo[3] = f0; fo[4] = f1; fo[5] = f2; }
     }
     SUBSTAMP(7);
@@ -631,20 +670,20 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
             WSYNC();
             const bool on = (lane < 60) && (d < nact);
             const int i = cb0 + (on ? d : 1);                      // parent of a depth >= 2 frame is i - 1
-            const double add = x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + fb + 6 * i, k);
-            const double old = L[fb + 6 * (i - 1) + k];
+            const R add = x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + fb + 6 * i, k);
+            const R old = L[fb + 6 * (i - 1) + k];
             if (on) L[fb + 6 * (i - 1) + k] = old + add;
         }
         WSYNC();
         SUBSTAMP(8);
         {   // the five chain roots project onto the base in parallel, then are summed in the reference's order
-            const double contrib = x_force(L + A_XE + 9 * cb0, L + A_XB + 9 * cb0, L + fb + 6 * cb0, k);
+            const R contrib = x_force(L + A_XE + 9 * cb0, L + A_XB + 9 * cb0, L + fb + 6 * cb0, k);
             if (lane < 60) L[A_VEL + 12 * c + 6 * which + k] = contrib;       // A_VEL is dead after the body forces
         }
         WSYNC();
         if (lane < 12) {                                           // base: head, LA, RA, LL, RL (Dynamics.cpp:157-162 order)
             const int w2 = lane / 6, k2 = lane % 6;
-            double acc = L[(w2 ? A_F0 : A_FG) + k2];
+            R acc = L[(w2 ? A_F0 : A_FG) + k2];
 #pragma unroll
             for (int cc = 4; cc >= 0; cc--) acc += L[A_VEL + 12 * cc + 6 * w2 + k2];
             if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc;
@@ -652,7 +691,7 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
         if (lane >= 16 && lane < 40) L[P_C + 6 + (lane - 16)] = L[A_FG + 6 * f_jframe(lane - 16) + 2];
         if (lane >= 40 && lane < 52) {                             // Jpqp = blkdiag(R,R) acc0[sole]
             const int foot = (lane - 40) / 6, k2 = (lane - 40) % 6, r = k2 % 3, o = (k2 / 3) * 3;
-            const double *T = L + P_TB + 12 * (1 + foot), *a = L + A_ACC0 + 6 * (foot ? 14 : 7);
+            const LV<R> T = L + P_TB + 12 * (1 + foot), a = L + A_ACC0 + 6 * (foot ? 14 : 7);
             L[P_JPQP + 6 * foot + k2] = T[4 * r] * a[o] + T[4 * r + 1] * a[o + 1] + T[4 * r + 2] * a[o + 2];
         }
     }
@@ -665,73 +704,76 @@ __device__ __forceinline__ void phase_newton_euler(double *L)
 // recursion never round-trips it through LDS; all five chains advance one level per pass.
 
 // rows of the 6x6 body inertia [Ibar, [h]x; -[h]x, m 1] (Dynamics.cpp:4-13): entries (r, 3cb..3cb+2)
-__device__ __forceinline__ void body_row3(const double *mo, int r, int cb, double out[3])
+template <typename R>
+__device__ __forceinline__ void body_row3(const LV<R> mo, int r, int cb, R out[3])
 {
     const bool up = r < 3;
     const int a = up ? r : r - 3;
-    const double hx = mo[9], hy = mo[10], hz = mo[11], m = mo[12];
-    const double c0 = (a == 0) ? 0.0 : (a == 1) ? hz : -hy;       // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]
-    const double c1 = (a == 0) ? -hz : (a == 1) ? 0.0 : hx;
-    const double c2 = (a == 0) ? hy : (a == 1) ? -hx : 0.0;
-    const double i0 = mo[3 * a], i1 = mo[3 * a + 1], i2 = mo[3 * a + 2];
+    const R hx = mo[9], hy = mo[10], hz = mo[11], m = mo[12];
+    const R c0 = (a == 0) ? 0.0 : (a == 1) ? hz : -hy;       // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]
+    const R c1 = (a == 0) ? -hz : (a == 1) ? 0.0 : hx;
+    const R c2 = (a == 0) ? hy : (a == 1) ? -hx : 0.0;
+    const R i0 = mo[3 * a], i1 = mo[3 * a + 1], i2 = mo[3 * a + 2];
     const bool diag = (up == (cb == 0));                           // (up, cb=0): Ibar row; (down, cb=1): m e_a
     out[0] = diag ? (up ? i0 : ((a == 0) ? m : 0.0)) : (up ? c0 : -c0);
     out[1] = diag ? (up ? i1 : ((a == 1) ? m : 0.0)) : (up ? c1 : -c1);
     out[2] = diag ? (up ? i2 : ((a == 2) ? m : 0.0)) : (up ? c2 : -c2);
 }
-__device__ __forceinline__ void crba_z(const double *L, int i, int slot, int r, int cb, double out[3])   // (X_i' Y)(r, 3cb..)
+template <typename R>
+__device__ __forceinline__ void crba_z(const LV<R> L, int i, int slot, int r, int cb, R out[3])   // (X_i' Y)(r, 3cb..)
 {
-    const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i, *Y = L + A_YT + 36 * slot + 3 * cb;
+    const LV<R> E = L + A_XE + 9 * i, Bm = L + A_XB + 9 * i, Y = L + A_YT + 36 * slot + 3 * cb;
     const bool up = r < 3;
     const int a = up ? r : r - 3;
-    const double lo0 = up ? E[3 * a] : 0.0, lo1 = up ? E[3 * a + 1] : 0.0, lo2 = up ? E[3 * a + 2] : 0.0;
-    const double hi0 = up ? Bm[a] : E[3 * a], hi1 = up ? Bm[3 + a] : E[3 * a + 1], hi2 = up ? Bm[6 + a] : E[3 * a + 2];
+    const R lo0 = up ? E[3 * a] : 0.0, lo1 = up ? E[3 * a + 1] : 0.0, lo2 = up ? E[3 * a + 2] : 0.0;
+    const R hi0 = up ? Bm[a] : E[3 * a], hi1 = up ? Bm[3 + a] : E[3 * a + 1], hi2 = up ? Bm[6 + a] : E[3 * a + 2];
 #pragma unroll
     for (int c = 0; c < 3; c++)
         out[c] = lo0 * Y[c] + lo1 * Y[6 + c] + lo2 * Y[12 + c] + hi0 * Y[18 + c] + hi1 * Y[24 + c] + hi2 * Y[30 + c];
 }
 
-__device__ __forceinline__ void phase_crba(double *L)
+template <typename R>
+__device__ __forceinline__ void phase_crba(LV<R> L)
 {
     const int lane = LANE;
     SUBSTAMP(9);
     const int ch = lane / 12, t = lane % 12, r = t >> 1, cb = t & 1;
     const int nact = (ch < 2) ? 6 : (ch < 4) ? 5 : 2;             // actuated frames of this lane's chain
     const int cbase = f_chain_base(ch < 5 ? ch : 4);
-    double ic[3] = {0.0, 0.0, 0.0};                               // Ic_i[r][3cb .. 3cb+2] of the frame being folded
+    R ic[3] = {0.0, 0.0, 0.0};                               // Ic_i[r][3cb .. 3cb+2] of the frame being folded
 #pragma unroll
     for (int dl = 6; dl >= 1; dl--) {                              // chain depth of the frames folded into their parents
         const bool on = (lane < 60) && (dl <= nact);
         const int i = cbase + (on ? dl - 1 : 0);                   // safe frame index for the idle lanes
-        double leaf[3];
+        R leaf[3];
         body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, r, cb, leaf);
         if (dl == nact) { ic[0] = leaf[0]; ic[1] = leaf[1]; ic[2] = leaf[2]; }   // leaf: Ic = I (Dynamics.cpp:72)
         if (on && cb == 0) L[A_FB + 6 * (f_act(i) - 1) + r] = ic[2];             // f = Ic_i S for the joint columns
-        const double p0 = dpp_row<0xB1>(ic[0]), p1 = dpp_row<0xB1>(ic[1]), p2 = dpp_row<0xB1>(ic[2]);   // partner lane ^ 1 (cb ^ 1)
-        const double lo[3] = {cb ? p0 : ic[0], cb ? p1 : ic[1], cb ? p2 : ic[2]};
-        const double hi[3] = {cb ? ic[0] : p0, cb ? ic[1] : p1, cb ? ic[2] : p2};
+        const R p0 = dpp_row<0xB1>(ic[0]), p1 = dpp_row<0xB1>(ic[1]), p2 = dpp_row<0xB1>(ic[2]);   // partner lane ^ 1 (cb ^ 1)
+        const R lo[3] = {cb ? p0 : ic[0], cb ? p1 : ic[1], cb ? p2 : ic[2]};
+        const R hi[3] = {cb ? ic[0] : p0, cb ? ic[1] : p1, cb ? ic[2] : p2};
         WSYNC();                                                   // A_YT of the previous level has been consumed
         {
-            const double *E = L + A_XE + 9 * i, *Bm = L + A_XB + 9 * i;
-            const double l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
-            double y[3];
+            const LV<R> E = L + A_XE + 9 * i, Bm = L + A_XB + 9 * i;
+            const R l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
+            R y[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const double x0 = cb ? E[3 * c] : Bm[c], x1 = cb ? E[3 * c + 1] : Bm[3 + c], x2 = cb ? E[3 * c + 2] : Bm[6 + c];
+                const R x0 = cb ? E[3 * c] : Bm[c], x1 = cb ? E[3 * c + 1] : Bm[3 + c], x2 = cb ? E[3 * c + 2] : Bm[6 + c];
                 y[c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + hi[0] * x0 + hi[1] * x1 + hi[2] * x2;
             }
-            if (on) { double *yo = L + A_YT + 36 * ch + 6 * r + 3 * cb; yo[0] = y[0]; yo[1] = y[1]; yo[2] = y[2]; }
+            if (on) { LV<R> yo = L + A_YT + 36 * ch + 6 * r + 3 * cb; yo[0] = y[0]; yo[1] = y[1]; yo[2] = y[2]; }
         }
         WSYNC();
         {
-            double z[3], bp3[3];
+            R z[3], bp3[3];
             crba_z(L, i, (lane < 60) ? ch : 0, r, cb, z);
             body_row3(L + P_MODEL + LMH_BODY_STRIDE * ((i > 0) ? i - 1 : 0), r, cb, bp3);
             if (dl >= 2) {                                         // Ic[parent] = Ic[parent] + X' Ic X (Dynamics.cpp:82), parent = i-1
                 if (on) { ic[0] = bp3[0] + z[0]; ic[1] = bp3[1] + z[1]; ic[2] = bp3[2] + z[2]; }
             } else if (on) {                                       // depth 1: park the contribution to the base
                 const int slot = (ch == 4) ? 0 : 4 - ch;           // reference order head, LA, RA, LL, RL
-                double *o = L + A_XR + 36 * slot + 6 * r + 3 * cb;
+                LV<R> o = L + A_XR + 36 * slot + 6 * r + 3 * cb;
                 o[0] = z[0]; o[1] = z[1]; o[2] = z[2];
             }
         }
@@ -739,14 +781,14 @@ __device__ __forceinline__ void phase_crba(double *L)
     WSYNC();
     SUBSTAMP(10);
     if (lane < 12) {                                               // Ic0 = I0 + head + LA + RA + LL + RL (Dynamics.cpp:80-82 order)
-        double acc[3];
+        R acc[3];
         body_row3(L + P_MODEL, r, cb, acc);
 #pragma unroll
         for (int sl = 0; sl < 5; sl++) {
-            const double *o = L + A_XR + 36 * sl + 6 * r + 3 * cb;
+            const LV<R> o = L + A_XR + 36 * sl + 6 * r + 3 * cb;
             acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
         }
-        double *mt = L + P_MTOP + 30 * r + 3 * cb;
+        LV<R> mt = L + P_MTOP + 30 * r + 3 * cb;
         mt[0] = acc[0]; mt[1] = acc[1]; mt[2] = acc[2];
     }
     WSYNC();
@@ -762,20 +804,20 @@ __device__ __forceinline__ void phase_crba(double *L)
         const int cur = (sdep - 1) & 1;
         const bool on = (lane < 48) && (sdep <= jd);
         const int j = on ? jf - (sdep - 1) : jf;                    // frame whose X' is applied
-        const double *E = L + A_XE + 9 * j, *Bm = L + A_XB + 9 * j, *f = L + A_FB + 144 * cur + 6 * ja;
-        const double *g = hf ? f + 3 : f;
-        double o3[3];
+        const LV<R> E = L + A_XE + 9 * j, Bm = L + A_XB + 9 * j, f = L + A_FB + 144 * cur + 6 * ja;
+        const LV<R> g = hf ? f + 3 : f;
+        R o3[3];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
-            const double t1 = E[3 * kk] * g[0] + E[3 * kk + 1] * g[1] + E[3 * kk + 2] * g[2];
-            const double t2 = Bm[kk] * f[3] + Bm[3 + kk] * f[4] + Bm[6 + kk] * f[5];
+            const R t1 = E[3 * kk] * g[0] + E[3 * kk + 1] * g[1] + E[3 * kk + 2] * g[2];
+            const R t2 = Bm[kk] * f[3] + Bm[3 + kk] * f[4] + Bm[6 + kk] * f[5];
             o3[kk] = hf ? t1 : t1 + t2;
         }
         if (on) {
-            double *fo = L + A_FB + 144 * (cur ^ 1) + 6 * ja + 3 * hf;
+            LV<R> fo = L + A_FB + 144 * (cur ^ 1) + 6 * ja + 3 * hf;
             fo[0] = o3[0]; fo[1] = o3[1]; fo[2] = o3[2];
             if (sdep == jd) {
-                double *mt = L + P_MTOP + 30 * (3 * hf) + 6 + ja;   // F2 column
+                LV<R> mt = L + P_MTOP + 30 * (3 * hf) + 6 + ja;   // F2 column
                 mt[0] = o3[0]; mt[30] = o3[1]; mt[60] = o3[2];
             } else if (hf == 0) {
                 const int aj = ja - sdep;                           // joint of parent(j)
@@ -789,7 +831,8 @@ __device__ __forceinline__ void phase_crba(double *L)
 
 // Kinematics::feetJacobian / frameJacobian (invKinematics.cpp:72-149), chain products in the
 // reference's association ((X7 X6) X5 ...); X kept as (A, B) with X = [A 0; B A].
-__device__ __forceinline__ void phase_jacobian(double *L)
+template <typename R>
+__device__ __forceinline__ void phase_jacobian(LV<R> L)
 {
     const int lane = LANE;
     const int foot = lane / 18, el = lane % 18, half = el / 9, r = (el % 9) / 3, c = el % 3;
@@ -802,10 +845,10 @@ __device__ __forceinline__ void phase_jacobian(double *L)
         WSYNC();
         const int f = sole - 1 - s;                                // frame 6..1 / 13..8
         if (lane < 36) {
-            const double *An = L + A_XN + 36 * cur + 18 * foot, *Bn = An + 9;
-            const double *E = L + A_XE + 9 * f, *Bf = L + A_XB + 9 * f;
+            const LV<R> An = L + A_XN + 36 * cur + 18 * foot, Bn = An + 9;
+            const LV<R> E = L + A_XE + 9 * f, Bf = L + A_XB + 9 * f;
             if (c == 2) L[A_JL + 72 * foot + 12 * (3 * half + r) + 6 + (5 - s)] = (half ? Bn : An)[3 * r + 2];   // Xn S
-            double val;                                            // A_f[k][c] = E[c][k]
+            R val;                                            // A_f[k][c] = E[c][k]
             if (!half) val = An[3 * r] * E[3 * c] + An[3 * r + 1] * E[3 * c + 1] + An[3 * r + 2] * E[3 * c + 2];
             else val = Bn[3 * r] * E[3 * c] + Bn[3 * r + 1] * E[3 * c + 1] + Bn[3 * r + 2] * E[3 * c + 2]
                      + An[3 * r] * Bf[c] + An[3 * r + 1] * Bf[3 + c] + An[3 * r + 2] * Bf[6 + c];
@@ -815,14 +858,14 @@ __device__ __forceinline__ void phase_jacobian(double *L)
     }
     WSYNC();
     if (lane < 36) {                                               // base block [A 0; B A]
-        const double *An = L + A_XN + 36 * cur + 18 * foot, *Bn = An + 9;
+        const LV<R> An = L + A_XN + 36 * cur + 18 * foot, Bn = An + 9;
         if (!half) { L[A_JL + 72 * foot + 12 * r + c] = An[3 * r + c]; L[A_JL + 72 * foot + 12 * r + 3 + c] = 0.0; L[A_JL + 72 * foot + 12 * (3 + r) + 3 + c] = An[3 * r + c]; }
         else L[A_JL + 72 * foot + 12 * (3 + r) + c] = Bn[3 * r + c];
     }
     WSYNC();
     for (int e = lane; e < 144; e += 64) {                         // rotate to world axes
         const int ft = e / 72, rr = (e % 72) / 12, col = e % 12, r3 = rr % 3, o = (rr / 3) * 3;
-        const double *T = L + P_TB + 12 * (1 + ft), *J = L + A_JL + 72 * ft + col;
+        const LV<R> T = L + P_TB + 12 * (1 + ft), J = L + A_JL + 72 * ft + col;
         L[P_JC + e] = T[4 * r3] * J[12 * o] + T[4 * r3 + 1] * J[12 * (o + 1)] + T[4 * r3 + 2] * J[12 * (o + 2)];
     }
     WSYNC();
@@ -1541,7 +1584,7 @@ __device__ __forceinline__ void phase_outputs(double *L)
 // call this with their wave index; every bsync below is reached by both (uniform control flow), all other fences
 // are wave-local.  Wave 1 never touches P_Q / P_V / the QP scratch after its last bsync, so wave 0 may run ahead
 // into the next evaluation's forward kinematics.
-template <int NW>
+template <int NW, typename R>
 __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
 {
     int flags = 0, ph = 0;
@@ -1549,10 +1592,10 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
 #define STAMP(i) do { if (dbg && LANE == 0) dbg[4000 + (i)] = (double)clock64(); } while (0)
     STAMP(0);
     const RefPrefetch pre = prefetch_refs(P, inst, t);
-    if (wid == 0) phase_fk(L, P.gcol + 228);
+    if (wid == 0) phase_fk<R>(L, P.gcol + 228);
     bsync<NW>();
     STAMP(1);
-    phase_com_x<NW>(L, wid);
+    phase_com_x<NW, R>(L, wid);
     bsync<NW>();
     STAMP(2);
     if (dbg) {
@@ -1562,14 +1605,14 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     }
     STAMP(3);
     if constexpr (NW == 1) {
-        phase_newton_euler(L);
+        phase_newton_euler<R>(L);
         STAMP(4);
-        phase_crba(L);
+        phase_crba<R>(L);
         STAMP(5);
-        phase_jacobian(L);
+        phase_jacobian<R>(L);
     } else {
-        if (wid == 0) { phase_newton_euler(L); phase_jacobian(L); }    // LDS regions of the three are disjoint
-        else phase_crba(L);
+        if (wid == 0) { phase_newton_euler<R>(L); phase_jacobian<R>(L); }    // LDS regions of the three are disjoint
+        else phase_crba<R>(L);
     }
     bsync<NW>();
     STAMP(6);
@@ -1650,7 +1693,7 @@ __device__ __forceinline__ void store_out(const double *L, double *out)
 // Controller::standStep + WBC for every instance (src/controller.cpp:48-154).
 // The plain kernel runs two waves per robot like the rollout; the debug kernel (intermediate dumps, stamps) keeps
 // the single-wave schedule.
-template <bool DEBUG>
+template <bool DEBUG, typename R>
 __global__ void __launch_bounds__(DEBUG ? 64 : LMH_ROLLOUT_THREADS) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
 {
     constexpr int NW = DEBUG ? 1 : 2;
@@ -1671,7 +1714,7 @@ __global__ void __launch_bounds__(DEBUG ? 64 : LMH_ROLLOUT_THREADS) lmh_eval_ker
     }
     bsync<NW>();
     int k = 0, iters = 0;
-    const int flags = controller_eval<NW>(L, P, inst, t, wid, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    const int flags = controller_eval<NW, R>(L, P, inst, t, wid, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
     if (wid == 0) {
         store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
         if (LANE < 30) st[60 + LANE] = L[P_V + LANE];              // Robot::v_ <- dq (controller.cpp:59)
@@ -1686,6 +1729,7 @@ __global__ void __launch_bounds__(DEBUG ? 64 : LMH_ROLLOUT_THREADS) lmh_eval_ker
 // Workgroup = LMH_ROLLOUT_THREADS = 2 waves per robot (see bsync): 4 robots = 8 waves per CU, two per SIMD, so the
 // kernel is held to 256 registers.  Wave 0 owns the RK4 state (lane i < 60 <-> component i) and everything
 // sequential; wave 1 joins for the phases controller_eval<2> splits.
+template <typename R>
 __global__ void __launch_bounds__(LMH_ROLLOUT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *log, int n_ticks)
 {
@@ -1718,7 +1762,7 @@ lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, 
                 if (lane < 60) L[P_Q + lane] = xs;
                 WSYNC();
             }
-            flags |= controller_eval<2>(L, P, inst, ts, wid, &F, &k, &iters, nullptr);
+            flags |= controller_eval<2, R>(L, P, inst, ts, wid, &F, &k, &iters, nullptr);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
                 // xdot (apps/offline/main.cpp:107-121)
@@ -1784,7 +1828,7 @@ __global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double
     for (int e = lane; e < 30; e += 64) L[P_Q + e] = 0.0;          // FK at q = 0
     load_tables(L);
     WSYNC();
-    phase_fk(L, lcoef);
+    phase_fk<double>(L, lcoef);
     double mloc = 0.0;
     if (lane < 28) {
         const double *T = L + A_T + 12 * lane, *lk = rw + LMH_LINK_STRIDE * lane;
@@ -1866,9 +1910,9 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
     const double mass = L[P_MODEL + 392];
     int iter = 0;
     for (;;) {
-        phase_fk(L, P.gcol + 228);
-        phase_com_x<1>(L, 0);
-        phase_jacobian(L);
+        phase_fk<double>(L, P.gcol + 228);
+        phase_com_x<1, double>(L, 0);
+        phase_jacobian<double>(L);
         // operationalState (:54-70)
         double Qv = 0.0;
         if (lane < 12) {
@@ -2019,8 +2063,8 @@ __global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P, const doubl
     if (LANE < 30) L[P_Q + LANE] = q[30 * (size_t)inst + LANE];
     if (LANE < 60) L[P_V + LANE] = 0.0;
     WSYNC();
-    phase_fk(L, P.gcol + 228);
-    phase_com_x<1>(L, 0);
+    phase_fk<double>(L, P.gcol + 228);
+    phase_com_x<1, double>(L, 0);
     if (LANE < 3) com[3 * (size_t)inst + LANE] = L[P_COM + LANE];
 }
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s)
@@ -2030,12 +2074,15 @@ extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *c
 
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s)
 {
-    if (debug) hipLaunchKernelGGL(lmh_eval_kernel<true>, dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
-    else hipLaunchKernelGGL(lmh_eval_kernel<false>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
+    // precision 1 (LMH_PRECISION_MIXED): model terms in fp32 arithmetic, references and QP in fp64; the debug kernel is fp64 only
+    if (debug) hipLaunchKernelGGL((lmh_eval_kernel<true, double>), dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
+    else if (P->precision == 1) hipLaunchKernelGGL((lmh_eval_kernel<false, float>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
+    else hipLaunchKernelGGL((lmh_eval_kernel<false, double>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
 }
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
 {
-    hipLaunchKernelGGL(lmh_rollout_kernel, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, log, n_ticks);
+    if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, log, n_ticks);
+    else hipLaunchKernelGGL(lmh_rollout_kernel<double>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, log, n_ticks);
 }
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s)
 {

@@ -473,6 +473,44 @@ def test_randomised_walking_config4_ingredients(cfg2):
             assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
 
 
+def test_mixed_precision_mode(cfg2):
+    """LMH_PRECISION_MIXED (BASELINE config 5's sweep): model terms in fp32 arithmetic, references + QP in fp64.
+    The preview index k stays bit-exact; tau / f land within 1e-4 of the fp64 oracle (they do NOT meet the 1e-6
+    bar: scripts/precision_sweep.py reports the distribution), flags stay clear, flight forces stay exactly zero."""
+    from linearmpchumanoid_amd import capi
+    B = 16
+    v = perturbed_velocities(B, seed=23)
+    outs = {}
+    for prec in (capi.PRECISION_FP64, capi.PRECISION_MIXED):
+        ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=1, precision=prec)
+        ctl.set_refs_stance(2.0, 2)
+        st = ctl.new_state(cfg2["q0"], v, t=0.0)
+        out, status, log = ctl.rollout(st, 12, log=True)
+        ev, evs = ctl.stand_step(st)                              # the plain evaluation kernel honours the mode too
+        torch.cuda.synchronize()
+        outs[prec] = (log.cpu().numpy(), status.cpu().numpy(), ev.cpu().numpy(), evs.cpu().numpy())
+    l64, s64, e64, es64 = outs[capi.PRECISION_FP64]
+    lmx, smx, emx, esmx = outs[capi.PRECISION_MIXED]
+    assert np.array_equal(s64[:, 0], smx[:, 0]) and np.array_equal(es64[:, 0], esmx[:, 0])     # k bit-exact in every mode
+    assert (smx[:, 2] == 0).all() and (esmx[:, 2] == 0).all()
+    for i in range(0, B, 4):
+        o = oracle_system(cfg2["dt"], cfg2["th"])
+        r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, 12, log=True)
+        for tk in range(12):
+            assert rel_err(l64[tk, i, :24], r["log"][tk][:24]) < TOL_REL
+            e_t, e_f = rel_err(lmx[tk, i, :24], r["log"][tk][:24]), rel_err(lmx[tk, i, 24:], r["log"][tk][24:])
+            assert 1e-9 < e_t < 1e-4 and e_f < 1e-4, (i, tk, e_t, e_f)     # fp32-sized, not fp64-sized, errors
+    assert rel_err(emx[:, :36], e64[:, :36]) < 1e-4
+    with pytest.raises(capi.LmhError):
+        make_controller(1, cfg2["dt"], cfg2["th"], cfg2["zcom"], precision=7)
+    ctl = make_controller(4, cfg2["dt"], cfg2["th"], cfg2["zcom"], precision=capi.PRECISION_MIXED)
+    ctl.set_refs(np.zeros(2500), np.zeros(2500), np.full(2500, 3, dtype=np.uint8))
+    st = ctl.new_state(cfg2["q0"], v[:4], t=0.0)
+    out, _, _ = ctl.rollout(st, 3)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy()[:, 24:36]).max() == 0.0      # flight: exactly no contact force in mixed mode too
+
+
 # ------------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("N", [48, 64])
 def test_long_horizons(cfg2, N):
