@@ -1,9 +1,10 @@
 // lmh_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the batched NAO controller.
 //
-// ONE WAVEFRONT (64 lanes) OWNS ONE ROBOT INSTANCE.  A workgroup is exactly one wave, so every
-// "barrier" below is a wave-level fence (hipcc lowers __syncthreads() of a 64-thread workgroup to a
-// wave barrier); all per-instance working data (kinematic tree, spatial inertias, mass matrix,
-// Jacobians, QP blocks) lives in ~40 KB of LDS (4 instances per CU = one wave per SIMD at B = 1024).
+// ONE WORKGROUP OWNS ONE ROBOT INSTANCE.  All per-instance working data (kinematic tree, spatial inertias, mass
+// matrix, Jacobians, QP blocks) lives in ~40 KB of LDS (4 instances per CU).  The fused rollout and the plain
+// evaluation kernel give a robot TWO waves (128 threads) that split the independent pieces of an evaluation and
+// join at workgroup barriers (see bsync / controller_eval); the debug, IK and model kernels run one wave.  Inside
+// a wave the "barriers" between LDS phases are wave-scope fences.
 // HBM is touched only for the 768-B state record in, the 640-B result out, the optional 288-B log per
 // tick and the shared read-only tables (model, MPC gain row, ZMP window) which stay L2-resident.
 //
@@ -22,8 +23,8 @@
 //     min 1/2 c'(G'WG + eps I)c - (G'h)'c, c >= 0: a 12x12 push-through solve when every coefficient
 //     is free, otherwise block principal pivoting from the previous active set with a Lawson-Hanson
 //     pass as the finite fall-back.
-//   * every SPD solve is a register-resident LDL' (row per lane, v_readlane pivot broadcast); the small
-//     dense products of the set-up run as v_mfma_f64_16x16x4_f64 tiles.
+//   * every SPD solve is a register-resident LDL' (row per lane; pivot broadcast by 64-bit DPP row_newbcast for
+//     N <= 16, v_readlane for N = 32); the small dense products of the set-up run as v_mfma_f64_16x16x4_f64 tiles.
 // The minimiser is unique (H is SPD), so this equals what qpOASES returns in the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
