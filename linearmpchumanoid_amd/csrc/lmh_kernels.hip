@@ -1118,51 +1118,51 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
 }
 
 
-// Compacted solve for |F| <= N: lane r < nF owns free index idx[r]; the N x N register LDL' then only
-// visits live pivots.  z of coefficient j comes back through LDS (P_CC).
+// Compacted solve for |F| <= N: lane r < nF owns the r-th free coefficient; the N x N register LDL' then only
+// visits live pivots.  F is wave-uniform, so the positions of its set bits come from a scalar bit-scan chain
+// (no LDS index table); z of coefficient j is read back from lane pos(j) with one lane permute.
 template <int N>
-__device__ __forceinline__ int solve_compact(double *L, int nF, int pos, bool inF)
+__device__ __forceinline__ int solve_compact(double *L, unsigned F, int nF, int pos, double *zj_out)
 {
     const int lane = LANE;
-    const int *idx = (const int *)(L + C_IDX);
     double a[N], b[1];
     {
+        int idx[N], ia = 0;
+        unsigned m = F;
+#pragma unroll
+        for (int c = 0; c < N; c++) {                              // idx[c] for c >= nF: 0, a valid (unused) index
+            idx[c] = m ? __builtin_ctz(m) : 0;
+            m &= m - 1u;
+            ia = (lane == c) ? idx[c] : ia;
+        }
         const bool on = lane < nF;
-        const int ia = on ? idx[lane] : 0;
         const double *Pr = L + C_P + 33 * ia;
 #pragma unroll
-        for (int c = 0; c < N; c++) a[c] = (on && c <= lane) ? Pr[idx[c]] : 0.0;     // idx[c] for c >= nF is a stale but valid index
+        for (int c = 0; c < N; c++) a[c] = (on && c <= lane) ? Pr[idx[c]] : 0.0;
         b[0] = on ? L[P_QV + ia] : 0.0;
     }
     const int bad = ldl_solve_regs<N, 1>(a, b, (nF >= 32) ? 0xFFFFFFFFu : ((1u << nF) - 1u), L + C_LS);
-    WSYNC();
-    if (lane < 32) L[P_CC + lane] = 0.0;
-    WSYNC();
-    if (lane < nF) L[P_CC + idx[lane]] = b[0];
-    WSYNC();
-    (void)pos; (void)inF;
+    *zj_out = __shfl(b[0], pos, 64);                               // coefficient j <- row pos(j)
     return bad;
 }
 
-// Solve P_FF z_F = qv_F on the free set F.  Returns z_j for lane j in F (0 otherwise) and, for lanes
-// j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
+// Solve P_FF z_F = qv_F on the free set F (wave-uniform).  Returns z_j for lane j in F (0 otherwise) and, for
+// lanes j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
 __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
 {
     const int lane = LANE, r = lane & 31, half = lane >> 5;
     const bool inF = (lane < 32) && ((F >> lane) & 1u);
     const int nF = __popc(F);
     const int pos = __popc(F & ((1u << r) - 1u));
-    int *idx = (int *)(L + C_IDX);
-    WSYNC();
-    if (lane < 32) idx[lane] = 0;
-    WSYNC();
-    if (inF) idx[pos] = lane;
-    WSYNC();
     int bad;
-    if (nF <= 8) bad = solve_compact<8>(L, nF, pos, inF);
-    else if (nF <= 16) bad = solve_compact<16>(L, nF, pos, inF);
-    else bad = solve_compact<32>(L, nF, pos, inF);
-    const double zj = (lane < 32) ? L[P_CC + lane] : 0.0;
+    double zr;
+    if (nF <= 8) bad = solve_compact<8>(L, F, nF, pos, &zr);
+    else if (nF <= 16) bad = solve_compact<16>(L, F, nF, pos, &zr);
+    else bad = solve_compact<32>(L, F, nF, pos, &zr);
+    const double zj = inF ? zr : 0.0;
+    WSYNC();
+    if (lane < 32) L[P_CC + lane] = zj;
+    WSYNC();
     double s = 0.0;
     {
         const double *Pr = L + C_P + 33 * r + 16 * half, *cc = L + P_CC + 16 * half;
@@ -1174,7 +1174,7 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_o
         const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(s), __double2hiint(s), false, false);
         s = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
     }
-    *z_out = inF ? zj : 0.0;
+    *z_out = zj;
     *lam_out = (lane < 32 && !((F >> lane) & 1u)) ? s - L[P_QV + r] : 0.0;
     return bad;
 }
@@ -1189,7 +1189,8 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
 {
     const int lane = LANE;
     int flags = 0, it = 0;
-    unsigned F = *F_io & ~forced;
+    forced = (unsigned)__builtin_amdgcn_readfirstlane((int)forced);
+    unsigned F = (unsigned)__builtin_amdgcn_readfirstlane((int)(*F_io & ~forced));    // scalar from here on (ballots keep it so)
     double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
     qmax = wave_max(qmax);
     const double toll = 1e-14 * (1.0 + qmax);                    // ~10x the round-off of (P c - q): a looser bound lets a warm start keep a coefficient
