@@ -278,34 +278,50 @@ __device__ __forceinline__ double bcast16(double x)               // compiler-vi
 // "VALU write -> DPP read" hazard on src for whatever the compiler placed before the block; inside the block
 // nothing writes src.  Must run with a full exec mask (wave-uniform control flow only).
 #define LMH_FD(k, s, m, c) "v_fmac_f64_dpp %" #k ", %" #s ", %" #m " row_newbcast:%" #c " row_mask:0xf bank_mask:0xf\n\t"
-template <int C0, int K, int N>
-__device__ __forceinline__ void dpp_fmac_cols(double (&a)[N], double src, double m)
+template <int A0, int B0, int K, int N>
+__device__ __forceinline__ void dpp_fmac_cols(double (&a)[N], double src, double m)    // a[A0 + k] += bcast16<B0 + k>(src) * m
 {
     static_assert(K == 1 || K == 2 || K == 4 || K == 8, "chunk size");
+    constexpr int C0 = A0;
     if constexpr (K == 8)
         asm volatile("s_nop 1\n\t" LMH_FD(0, 8, 9, 10) LMH_FD(1, 8, 9, 11) LMH_FD(2, 8, 9, 12) LMH_FD(3, 8, 9, 13)
                      LMH_FD(4, 8, 9, 14) LMH_FD(5, 8, 9, 15) LMH_FD(6, 8, 9, 16) LMH_FD(7, 8, 9, 17)
                      : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]), "+v"(a[C0 + 4]), "+v"(a[C0 + 5]), "+v"(a[C0 + 6]), "+v"(a[C0 + 7])
-                     : "v"(src), "v"(m), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3), "n"(C0 + 4), "n"(C0 + 5), "n"(C0 + 6), "n"(C0 + 7));
+                     : "v"(src), "v"(m), "n"(B0), "n"(B0 + 1), "n"(B0 + 2), "n"(B0 + 3), "n"(B0 + 4), "n"(B0 + 5), "n"(B0 + 6), "n"(B0 + 7));
     else if constexpr (K == 4)
         asm volatile("s_nop 1\n\t" LMH_FD(0, 4, 5, 6) LMH_FD(1, 4, 5, 7) LMH_FD(2, 4, 5, 8) LMH_FD(3, 4, 5, 9)
                      : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3])
-                     : "v"(src), "v"(m), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
+                     : "v"(src), "v"(m), "n"(B0), "n"(B0 + 1), "n"(B0 + 2), "n"(B0 + 3));
     else if constexpr (K == 2)
         asm volatile("s_nop 1\n\t" LMH_FD(0, 2, 3, 4) LMH_FD(1, 2, 3, 5)
-                     : "+v"(a[C0]), "+v"(a[C0 + 1]) : "v"(src), "v"(m), "n"(C0), "n"(C0 + 1));
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]) : "v"(src), "v"(m), "n"(B0), "n"(B0 + 1));
     else
-        asm volatile("s_nop 1\n\t" LMH_FD(0, 1, 2, 3) : "+v"(a[C0]) : "v"(src), "v"(m), "n"(C0));
+        asm volatile("s_nop 1\n\t" LMH_FD(0, 1, 2, 3) : "+v"(a[C0]) : "v"(src), "v"(m), "n"(B0));
 }
 // a[c] += bcast16<c>(src) * m for c in [C0, N)
 template <int C0, int N>
 __device__ __forceinline__ void dpp_fmac_tail(double (&a)[N], double src, double m)
 {
     constexpr int R = N - C0;
-    if constexpr (R >= 8) { dpp_fmac_cols<C0, 8>(a, src, m); dpp_fmac_tail<C0 + 8>(a, src, m); }
-    else if constexpr (R >= 4) { dpp_fmac_cols<C0, 4>(a, src, m); dpp_fmac_tail<C0 + 4>(a, src, m); }
-    else if constexpr (R >= 2) { dpp_fmac_cols<C0, 2>(a, src, m); dpp_fmac_tail<C0 + 2>(a, src, m); }
-    else if constexpr (R == 1) { dpp_fmac_cols<C0, 1>(a, src, m); }
+    if constexpr (R >= 8) { dpp_fmac_cols<C0, C0, 8>(a, src, m); dpp_fmac_tail<C0 + 8>(a, src, m); }
+    else if constexpr (R >= 4) { dpp_fmac_cols<C0, C0, 4>(a, src, m); dpp_fmac_tail<C0 + 4>(a, src, m); }
+    else if constexpr (R >= 2) { dpp_fmac_cols<C0, C0, 2>(a, src, m); dpp_fmac_tail<C0 + 2>(a, src, m); }
+    else if constexpr (R == 1) { dpp_fmac_cols<C0, C0, 1>(a, src, m); }
+}
+// a[A0 + k] += bcast16<B0 + k>(src) * m for k < CNT
+template <int A0, int B0, int CNT, int N>
+__device__ __forceinline__ void dpp_fmac_range(double (&a)[N], double src, double m)
+{
+    if constexpr (CNT >= 8) { dpp_fmac_cols<A0, B0, 8>(a, src, m); dpp_fmac_range<A0 + 8, B0 + 8, CNT - 8>(a, src, m); }
+    else if constexpr (CNT >= 4) { dpp_fmac_cols<A0, B0, 4>(a, src, m); dpp_fmac_range<A0 + 4, B0 + 4, CNT - 4>(a, src, m); }
+    else if constexpr (CNT >= 2) { dpp_fmac_cols<A0, B0, 2>(a, src, m); dpp_fmac_range<A0 + 2, B0 + 2, CNT - 2>(a, src, m); }
+    else if constexpr (CNT == 1) { dpp_fmac_cols<A0, B0, 1>(a, src, m); }
+}
+// acc += bcast16<J>(src) * m (acc and src may be the same register)
+template <int J>
+__device__ __forceinline__ void dpp_fmac_one(double &acc, double src, double m)
+{
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(J));
 }
 // b[r] += bcast16<J>(b[r]) * m for r < M (each right-hand side broadcasts its own lane-J entry)
 #define LMH_FS(k, m, c) "v_fmac_f64_dpp %" #k ", %" #k ", %" #m " row_newbcast:%" #c " row_mask:0xf bank_mask:0xf\n\t"
@@ -353,6 +369,95 @@ __device__ __forceinline__ void ldl16_backward(double (&b)[M], unsigned live, in
         }
         ldl16_backward<J - 1, N>(b, live, lane, Ls);
     }
+}
+
+// ---- 16 < N <= 32, one right-hand side: TWO matrix rows per lane so that every row lives in DPP row 0 and the
+// pivot broadcast is again a row_newbcast.  Lane i < 16 holds row i in a0[0..15] and row 16 + i in a1[0..N-1]
+// (lower triangles), rhs entries b0 / b1.  Pivot J < 16: the scaled pivot column sits in a0[J] (rows < 16, lane c)
+// and a1[J] (rows >= 16, lane c - 16); pivot J >= 16: in a1[J].
+template <int J, int N2>
+__device__ __forceinline__ void ldl2_forward(double (&a0)[16], double (&a1)[16 + N2], double &b0, double &b1, unsigned live, int lane,
+                                             int &bad, double &inv0, double &inv1)
+{
+    constexpr int N = 16 + N2;
+    if constexpr (J < N) {
+        if ((live >> J) & 1u) {                                   // wave-uniform
+            if constexpr (J < 16) {
+                double d = bcast16<J>(a0[J]);
+                d = (lane < 16) ? d : 1.0;
+                if (!(d > 0.0)) bad = 1;
+                const double invd = fast_rcp(d);
+                const double f0 = a0[J] * invd, f1 = a1[J] * invd;     // L_iJ (rows < 16, valid for lane > J) | L_(16+i)J
+                const double nfm0 = (lane > J) ? -f0 : 0.0;
+                if (lane == J) inv0 = invd;
+                dpp_fmac_range<J + 1, J + 1, 15 - J>(a0, a0[J], -f0);  // columns J+1..15: lane c holds d_J L_cJ in a0[J]
+                dpp_fmac_range<J + 1, J + 1, 15 - J>(a1, a0[J], -f1);
+                dpp_fmac_range<16, 0, N2>(a1, a1[J], -f1);             // columns 16..N-1: lane c - 16 holds d_J L_cJ in a1[J]
+                dpp_fmac_one<J>(b1, b0, -f1);                          // forward substitution (lane J's b0 is z_J, untouched below)
+                dpp_fmac_one<J>(b0, b0, nfm0);
+                if (lane > J) a0[J] = f0;
+                a1[J] = f1;
+            } else {
+                constexpr int Jp = J - 16;
+                double d = bcast16<Jp>(a1[J]);
+                d = (lane < 16) ? d : 1.0;
+                if (!(d > 0.0)) bad = 1;
+                const double invd = fast_rcp(d);
+                const double f1 = a1[J] * invd;
+                const double nfm1 = (lane > Jp) ? -f1 : 0.0;
+                if (lane == Jp) inv1 = invd;
+                dpp_fmac_range<J + 1, Jp + 1, N - 1 - J>(a1, a1[J], -f1);
+                dpp_fmac_one<Jp>(b1, b1, nfm1);
+                if (lane > Jp) a1[J] = f1;
+            }
+        }
+        ldl2_forward<J + 1, N2>(a0, a1, b0, b1, live, lane, bad, inv0, inv1);
+    }
+}
+template <int J, int N2>
+__device__ __forceinline__ void ldl2_backward(double &b0, double &b1, unsigned live, int lane, const double *Ls)
+{
+    constexpr int N = 16 + N2;
+    if constexpr (J > 0) {
+        if ((live >> J) & 1u) {
+            const int l16 = (lane < 16) ? lane : 0;                // lanes outside DPP row 0 read a valid address
+            if constexpr (J >= 16) {
+                constexpr int Jp = J - 16;
+                const double l0 = (lane < 16) ? Ls[J * (N + 1) + l16] : 0.0;             // L[J][lane], rows < 16
+                const double l1 = (lane < Jp) ? Ls[J * (N + 1) + 16 + l16] : 0.0;        // L[J][16 + lane], rows 16 .. J-1
+                dpp_fmac_one<Jp>(b0, b1, -l0);
+                dpp_fmac_one<Jp>(b1, b1, -l1);
+            } else {
+                const double l0 = (lane < J) ? Ls[J * (N + 1) + l16] : 0.0;
+                dpp_fmac_one<J>(b0, b0, -l0);
+            }
+        }
+        ldl2_backward<J - 1, N2>(b0, b1, live, lane, Ls);
+    }
+}
+// On exit b0 of lane i < 16 holds x_i and b1 holds x_(16+i).  Returns non-zero (wave-uniform) if a pivot was not positive.
+template <int N2>
+__device__ __forceinline__ int ldl2_solve_regs(double (&a0)[16], double (&a1)[16 + N2], double &b0, double &b1, unsigned live, double *Ls)
+{
+    constexpr int N = 16 + N2;
+    const int lane = LANE;
+    int bad = 0;
+    double inv0 = 0.0, inv1 = 0.0;
+    ldl2_forward<0, N2>(a0, a1, b0, b1, live, lane, bad, inv0, inv1);
+    bad = __builtin_amdgcn_readfirstlane(bad);
+    b0 *= inv0; b1 *= inv1;                                       // w = D^-1 z
+    WSYNC();
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 15; c++) Ls[lane * (N + 1) + c] = a0[c];                 // L[lane][c], c < lane
+    }
+    if (lane < N2) {
+#pragma unroll
+        for (int c = 0; c < N - 1; c++) Ls[(16 + lane) * (N + 1) + c] = a1[c];       // L[16 + lane][c], c < 16 + lane
+    }
+    WSYNC();
+    ldl2_backward<N - 1, N2>(b0, b1, live, lane, Ls);
+    return bad;
 }
 
 // Register-resident LDL' solve of an SPD system with M right-hand sides, N <= 32.
@@ -1146,6 +1251,36 @@ __device__ __forceinline__ int solve_compact(double *L, unsigned F, int nF, int 
     return bad;
 }
 
+// |F| in 17..32: two rows per lane (ldl2_solve_regs); coefficient of compact row r < 16 in lane r (b0), of row
+// r >= 16 in lane r - 16 (b1).
+__device__ __forceinline__ int solve_compact2(double *L, unsigned F, int nF, int pos, double *zj_out)
+{
+    const int lane = LANE;
+    double a0[16], a1[32], b0, b1;
+    {
+        int idx[32], ia0 = 0, ia1 = 0;
+        unsigned m = F;
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            idx[c] = m ? __builtin_ctz(m) : 0;
+            m &= m - 1u;
+            if (c < 16) ia0 = (lane == c) ? idx[c] : ia0; else ia1 = (lane == c - 16) ? idx[c] : ia1;
+        }
+        const bool on0 = (lane < 16) && (lane < nF), on1 = (lane < 16) && (16 + lane < nF);
+        const double *P0 = L + C_P + 33 * ia0, *P1 = L + C_P + 33 * ia1;
+#pragma unroll
+        for (int c = 0; c < 16; c++) a0[c] = (on0 && c <= lane) ? P0[idx[c]] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 32; c++) a1[c] = (on1 && c <= 16 + lane) ? P1[idx[c]] : 0.0;
+        b0 = on0 ? L[P_QV + ia0] : 0.0;
+        b1 = on1 ? L[P_QV + ia1] : 0.0;
+    }
+    const int bad = ldl2_solve_regs<16>(a0, a1, b0, b1, (nF >= 32) ? 0xFFFFFFFFu : ((1u << nF) - 1u), L + C_LS);
+    const double z0 = __shfl(b0, pos & 15, 64), z1 = __shfl(b1, pos & 15, 64);
+    *zj_out = (pos < 16) ? z0 : z1;                                // coefficient j <- compact row pos(j)
+    return bad;
+}
+
 // Solve P_FF z_F = qv_F on the free set F (wave-uniform).  Returns z_j for lane j in F (0 otherwise) and, for
 // lanes j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
 __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
@@ -1158,7 +1293,7 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_o
     double zr;
     if (nF <= 8) bad = solve_compact<8>(L, F, nF, pos, &zr);
     else if (nF <= 16) bad = solve_compact<16>(L, F, nF, pos, &zr);
-    else bad = solve_compact<32>(L, F, nF, pos, &zr);
+    else bad = solve_compact2(L, F, nF, pos, &zr);
     const double zj = inF ? zr : 0.0;
     WSYNC();
     if (lane < 32) L[P_CC + lane] = zj;

@@ -53,3 +53,11 @@ rows = [("fk:sincos", st_[:,0], ss[:,0]), ("fk:Lc+T0 build", ss[:,0], ss[:,1]), 
         ("refs:AG", st_[:,6], ss[:,12]), ("refs:h,vfoot,pdj", ss[:,12], ss[:,13]), ("refs:mpc", ss[:,13], ss[:,14]), ("refs:pd mom/feet", ss[:,14], st_[:,7])]
 for n, a, b in rows:
     print("  %-20s %8.0f cycles" % (n, seg(a, b)))
+
+# distribution of the free-set size and what it costs (the launch time of the rollout is set by the slowest robot)
+nF = np.array([bin((~int(x)) & 0xFFFFFFFF).count("1") for x in s[:, 3]])
+print("free-set size |F| histogram (warm):")
+for lo, hi in ((0, 8), (9, 16), (17, 24), (25, 31), (32, 32)):
+    m = (nF >= lo) & (nF <= hi)
+    if m.sum():
+        print("  |F| in [%2d,%2d]: %4d robots  mean eval cycles %7.0f  qp %7.0f  max %7.0f" % (lo, hi, m.sum(), tot[m].mean(), dur[m, 7].mean(), tot[m].max()))
