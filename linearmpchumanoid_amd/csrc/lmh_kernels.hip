@@ -1314,6 +1314,137 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_o
     return bad;
 }
 
+// ---- push-through solve on a free set F (generalises the all-free fast path of cone_qp).
+// With G_F the generators of the free coefficients and K = G_F G_F' = blkdiag(K_R, K_L) (6 x 6 per foot), the
+// minimiser of 1/2 c'(G'WG + eps I)c - (G'h)'c over c_F (other coefficients 0) is c_F = G_F' y, y = K^-1 w, where the
+// wrench w = G_F c_F solves the 12 x 12 SPD system (W + eps K^-1) w = h -- PROVIDED each foot with a free
+// coefficient has K_f nonsingular (its free generators span the foot's wrench space).  Then also
+// (P c - q)_j = g_j'(W w - h) = -eps g_j' y for j outside F, so one vector s_j = g_j' y (j < 32) carries both the
+// coefficients (j in F) and the multipliers (-eps s_j, j not in F; for a foot without free coefficients y is
+// replaced by -(W w - h)/eps, the residual itself).  Two 6 x 6 inversions (both feet at once, one
+// per DPP row) and a 12 x 12 solve replace the |F| x |F| factorisation.  A foot without any free coefficient
+// carries no force (its rows are dropped).  Returns 0 (wave-uniform) when some K_f is numerically singular: the
+// caller then takes the general P_FF solve.
+template <int J>
+__device__ __forceinline__ void ldl6_pair_step(double (&a)[6], double (&b)[6], int l16, bool rowon, int &bad, double &myinv)
+{
+    if constexpr (J < 6) {
+        double d = bcast16<J>(a[J]);                               // lane J of each DPP row: that foot's pivot
+        if (rowon && !(d > 1e-12)) bad = 1;                        // K_f entries are O(1e-3 .. 10); a rank-deficient block pivots at ~1e-17
+        d = (rowon && d > 1e-12) ? d : 1.0;
+        const double invd = fast_rcp(d);
+        const double f = a[J] * invd;
+        const double nfm = (l16 > J) ? -f : 0.0;
+        if (l16 == J) myinv = invd;
+        dpp_fmac_tail<J + 1>(a, a[J], -f);
+        dpp_fmac_rhs<J>(b, nfm);
+        if (l16 > J) a[J] = f;
+        ldl6_pair_step<J + 1>(a, b, l16, rowon, bad, myinv);
+    }
+}
+template <int J>
+__device__ __forceinline__ void ldl6_pair_back(double (&b)[6], int l16, const double *Lrow)
+{
+    if constexpr (J > 0) {
+        const double nl = (l16 < J) ? -Lrow[7 * J + ((l16 < 6) ? l16 : 0)] : 0.0;
+        dpp_fmac_rhs<J>(b, nl);
+        ldl6_pair_back<J - 1>(b, l16, Lrow);
+    }
+}
+__device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P, unsigned F, double *s_out, int *flags)
+{
+    const int lane = LANE, l16 = lane & 15, row = lane >> 4;
+    const unsigned FR = F & 0xFFFFu, FL = F >> 16;
+    const bool useR = FR != 0u, useL = FL != 0u;
+    double *K = L + C_LS, *Ki = L + C_LS + 72, *Yv = L + C_LS + 144, *Ls = L + C_LS + 200;
+    WSYNC();
+    for (int e = lane; e < 72; e += 64) {                          // K_f[r][c] = sum over the free generators of foot f
+        const int f = e / 36, r = (e % 36) / 6, c = e % 6;
+        const unsigned m = f ? FL : FR;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double g = L[P_GCOL + 6 * j + r] * L[P_GCOL + 6 * j + c];
+            acc += ((m >> j) & 1u) ? g : 0.0;
+        }
+        K[e] = acc;
+    }
+    WSYNC();
+    int bad = 0;
+    {   // both 6 x 6 inverses at once: DPP row 0 = right foot, DPP row 1 = left foot (six unit right-hand sides each)
+        const bool rowon = (row == 0 && useR) || (row == 1 && useL);
+        const bool on = rowon && l16 < 6;
+        const int rb = (row < 2) ? 36 * row : 0, lr = (l16 < 6) ? l16 : 0;
+        double a[6], bb[6], myinv = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { a[c] = (on && c <= l16) ? K[rb + 6 * lr + c] : 0.0; bb[c] = (on && l16 == c) ? 1.0 : 0.0; }
+        ldl6_pair_step<0>(a, bb, l16, rowon, bad, myinv);
+#pragma unroll
+        for (int c = 0; c < 6; c++) bb[c] *= myinv;
+        WSYNC();
+        if (row < 2 && l16 < 6) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) Ls[42 * row + 7 * l16 + c] = a[c];
+        }
+        WSYNC();
+        ldl6_pair_back<5>(bb, l16, Ls + ((row < 2) ? 42 * row : 0));
+        if (row < 2 && l16 < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) Ki[36 * row + 6 * l16 + c] = on ? bb[c] : 0.0;       // K_f^-1 (symmetric); 0 for a foot without force
+        }
+    }
+    const unsigned badm = (unsigned)__ballot(bad != 0);
+    if (badm != 0u) return 0;                                      // wave-uniform: some K_f is singular
+    WSYNC();
+    {   // (W + eps K^-1) w = h on the rows of the feet that carry force
+        double a[12], b[1];
+        const int fi = lane / 6, ri = lane % 6;
+        const bool rowuse = (lane < 12) && ((fi == 0) ? useR : useL);
+#pragma unroll
+        for (int c = 0; c < 12; c++) {
+            double v = 0.0;
+            const bool coluse = (c < 6) ? useR : useL;
+            if (rowuse && coluse && c <= lane) {
+                v = L[P_W + 12 * lane + c];
+                if (c / 6 == fi) v += P.eps_coeff * Ki[36 * fi + 6 * ri + c % 6];
+            }
+            a[c] = v;
+        }
+        b[0] = rowuse ? L[P_H12 + lane] : 0.0;
+        const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
+        if (ldl_solve_regs<12, 1>(a, b, live, Ls)) *flags |= LMH_FLAG_NOT_SPD;
+        WSYNC();
+        if (lane < 12) Yv[lane] = rowuse ? b[0] : 0.0;             // w
+    }
+    WSYNC();
+    if (lane < 12) {                                               // y = K^-1 w, foot by foot
+        const int fi = lane / 6, ri = lane % 6;
+        const bool used = (fi == 0) ? useR : useL;
+        double yv = 0.0;
+        if (used) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) yv += Ki[36 * fi + 6 * ri + k] * Yv[6 * fi + k];
+        } else {
+            // a foot with no free coefficient: its multipliers are g_j'(W w - h) with the foot's rows of the residual;
+            // stored as -(W w - h)/eps so that the caller's -eps s_j reproduces them
+            double rv = -L[P_H12 + lane];
+#pragma unroll
+            for (int k = 0; k < 12; k++) rv += L[P_W + 12 * lane + k] * Yv[k];
+            yv = -rv / P.eps_coeff;
+        }
+        Yv[12 + lane] = yv;
+    }
+    WSYNC();
+    double sj = 0.0;
+    if (lane < 32) {
+        const double *g = L + P_GCOL + 6 * (lane & 15), *y = Yv + 12 + 6 * (lane >> 4);
+#pragma unroll
+        for (int k = 0; k < 6; k++) sj += g[k] * y[k];
+    }
+    *s_out = sj;
+    return 1;
+}
+
 // min 1/2 c'Pc - qv'c  s.t. c >= 0, c_j = 0 for j in `forced`.  P = G'WG + eps I is SPD, so the
 // minimiser is unique.  Fast path: block principal pivoting from the incoming free set (one solve when
 // the active set did not change, typically <= 8 from a cold start).  If that has not settled after
@@ -1380,7 +1511,12 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         it++;
         double zj;
         if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
-        if (solve_free_set(L, F, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+        double sj;
+        if (!lh && cone_pushthrough(L, P, F, &sj, &flags)) {       // 12 x 12 route: coefficients and multipliers from one vector
+            const bool fr = (lane < 32) && ((F >> lane) & 1u);
+            zj = fr ? sj : 0.0;
+            lj = (lane < 32 && !fr) ? -P.eps_coeff * sj : 0.0;
+        } else if (solve_free_set(L, F, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
         if (dbgp && lane == 0 && it <= 12) { dbgp[4021 + 2 * it] = (double)clock64(); dbgp[4050 + it] = (double)__popc(F); }
         const bool inF = (lane < 32) && ((F >> lane) & 1u);
         if (!lh) {

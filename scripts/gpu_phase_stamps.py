@@ -60,4 +60,5 @@ print("free-set size |F| histogram (warm):")
 for lo, hi in ((0, 8), (9, 16), (17, 24), (25, 31), (32, 32)):
     m = (nF >= lo) & (nF <= hi)
     if m.sum():
-        print("  |F| in [%2d,%2d]: %4d robots  mean eval cycles %7.0f  qp %7.0f  max %7.0f" % (lo, hi, m.sum(), tot[m].mean(), dur[m, 7].mean(), tot[m].max()))
+        cone = (q[m, 3] - q[m, 2]).mean(); s1 = (d[m, 4023] - d[m, 4022]).mean()
+        print("  |F| in [%2d,%2d]: %4d robots  mean eval cycles %7.0f  qp %7.0f  max %7.0f  | cone phase %6.0f  free-set solve #1 %6.0f  iters %.2f" % (lo, hi, m.sum(), tot[m].mean(), dur[m, 7].mean(), tot[m].max(), cone, s1, s[m, 1].mean()))
