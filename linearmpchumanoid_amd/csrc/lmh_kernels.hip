@@ -1358,16 +1358,19 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
     const bool useR = FR != 0u, useL = FL != 0u;
     double *K = L + C_LS, *Ki = L + C_LS + 72, *Yv = L + C_LS + 144, *Ls = L + C_LS + 200;
     WSYNC();
-    for (int e = lane; e < 72; e += 64) {                          // K_f[r][c] = sum over the free generators of foot f
-        const int f = e / 36, r = (e % 36) / 6, c = e % 6;
-        const unsigned m = f ? FL : FR;
-        double acc = 0.0;
+    {   // K_f = G diag(free_f) G' for both feet as ONE 16 x 16 x 16 matrix-core product: row block f of A carries foot f's
+        // mask, so the two diagonal 6 x 6 blocks of the tile are K_R and K_L (the off-diagonal blocks are not used)
+        auto a_g = [=](int m, int k) { const unsigned msk = (m < 6) ? FR : FL; const bool ok = (m < 12) && ((msk >> k) & 1u);
+                                       return ldz(L, ok, P_GCOL + 6 * k + ((m < 6) ? m : m - 6), P_GCOL); };
+        auto b_g = [=](int k, int n) { return ldz(L, n < 12, P_GCOL + 6 * k + ((n < 6) ? n : n - 6), P_GCOL); };
+        const v4d kk = mfma_tile<4>(a_g, b_g);
+        const int tr = lane & 15, tq = lane >> 4;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const double g = L[P_GCOL + 6 * j + r] * L[P_GCOL + 6 * j + c];
-            acc += ((m >> j) & 1u) ? g : 0.0;
+        for (int g = 0; g < 4; g++) {
+            const int rw = tq + 4 * g;
+            const int fr = (rw >= 6) ? 1 : 0, fc = (tr >= 6) ? 1 : 0;
+            if (rw < 12 && tr < 12 && fr == fc) K[36 * fr + 6 * (rw - 6 * fr) + (tr - 6 * fc)] = kk[g];
         }
-        K[e] = acc;
     }
     WSYNC();
     int bad = 0;
