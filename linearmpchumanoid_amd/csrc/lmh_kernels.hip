@@ -1223,6 +1223,40 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
 }
 
 
+// Cone Hessian for the general free-set solve: WG = W G (12 x 32), P = G' WG + eps I (32 x 32), six MFMA tiles.
+// Formed lazily (cone_qp): the push-through route never reads it.
+__device__ __forceinline__ void build_cone_matrix(double *L, const LmhDevParams &P)
+{
+    const int lane = LANE, tr = lane & 15, tq = lane >> 4;
+    WSYNC();
+    {
+        auto a_w = [=](int m, int k) { return ldz(L, m < 12 && k < 12, P_W + 12 * m + k, P_W); };
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            auto b_g = [=](int k, int n) { const int kk = k - 6 * nt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * n + kk, P_GCOL); };
+            const v4d wg = mfma_tile<3>(a_w, b_g);
+#pragma unroll
+            for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12) L[C_WG + 32 * row + 16 * nt + tr] = wg[g]; }
+        }
+    }
+    WSYNC();
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        auto a_gt = [=](int m, int k) { const int kk = k - 6 * mt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * m + kk, P_GCOL); };
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            auto b_wg = [=](int k, int n) { return ldz(L, k < 12, C_WG + 32 * k + 16 * nt + n, C_WG); };
+            const v4d pp = mfma_tile<3>(a_gt, b_wg);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int i = 16 * mt + tq + 4 * g, j = 16 * nt + tr;
+                L[C_P + 33 * i + j] = pp[g] + ((i == j) ? P.eps_coeff : 0.0);
+            }
+        }
+    }
+    WSYNC();
+}
+
 // Compacted solve for |F| <= N: lane r < nF owns the r-th free coefficient; the N x N register LDL' then only
 // visits live pivots.  F is wave-uniform, so the positions of its set bits come from a scalar bit-scan chain
 // (no LDS index table); z of coefficient j is read back from lane pos(j) with one lane permute.
@@ -1467,6 +1501,8 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
     const bool mine = (lane < 32) && !((forced >> lane) & 1u);
     int ninf = 33, budget = 3;
     bool lh = false;                                               // false: block pivoting, true: Lawson-Hanson
+    bool have_p = false;                                           // cone Hessian formed (general solve only)
+    if (dbgp) { build_cone_matrix(L, P); have_p = true; }          // the debug record dumps it
     double cj = 0.0, lj = 0.0;
     if (forced == 0u && F == 0xFFFFFFFFu) {
         // every coefficient free (the usual balance case): then w = G c solves the 12 x 12 SPD system
@@ -1519,7 +1555,10 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
             const bool fr = (lane < 32) && ((F >> lane) & 1u);
             zj = fr ? sj : 0.0;
             lj = (lane < 32 && !fr) ? -P.eps_coeff * sj : 0.0;
-        } else if (solve_free_set(L, F, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+        } else {
+            if (!have_p) { build_cone_matrix(L, P); have_p = true; }
+            if (solve_free_set(L, F, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+        }
         if (dbgp && lane == 0 && it <= 12) { dbgp[4021 + 2 * it] = (double)clock64(); dbgp[4050 + it] = (double)__popc(F); }
         const bool inF = (lane < 32) && ((F >> lane) & 1u);
         if (!lh) {
@@ -1735,44 +1774,19 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         }
     }
     }
-    bsync<NW>();
     if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
-    // ---- cone QP data: WG = W G (12 x 32), Pm = G' WG + eps I (32 x 32), qv = G' h ; G[k][j] is the
-    //      generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
-    {
-        auto a_w = [=](int m, int k) { return ldz(L, m < 12 && k < 12, P_W + 12 * m + k, P_W); };
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            if (NW == 2 && nt != wid) continue;                    // one column tile per wave
-            auto b_g = [=](int k, int n) { const int kk = k - 6 * nt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * n + kk, P_GCOL); };
-            const v4d wg = mfma_tile<3>(a_w, b_g);
-#pragma unroll
-            for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12) L[C_WG + 32 * row + 16 * nt + tr] = wg[g]; }
+    // ---- qv = G' h (the cone Hessian G'WG + eps I itself is only formed if the general free-set solve is needed,
+    //      build_cone_matrix); G[k][j] is the generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
+    if (wid == 0) {
+        WSYNC();
+        if (lane < 32) {
+            const int o = 6 * (lane / 16);
+            double sacc = 0.0;
+            for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
+            L[P_QV + lane] = sacc;
         }
+        WSYNC();
     }
-    if (wid == 0 && lane < 32) {
-        const int o = 6 * (lane / 16);
-        double sacc = 0.0;
-        for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
-        L[P_QV + lane] = sacc;
-    }
-    bsync<NW>();
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-        if (NW == 2 && mt != wid) continue;                        // two of the four tiles per wave
-        auto a_gt = [=](int m, int k) { const int kk = k - 6 * mt; return ldz(L, kk >= 0 && kk < 6, P_GCOL + 6 * m + kk, P_GCOL); };
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            auto b_wg = [=](int k, int n) { return ldz(L, k < 12, C_WG + 32 * k + 16 * nt + n, C_WG); };
-            const v4d pp = mfma_tile<3>(a_gt, b_wg);
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int i = 16 * mt + tq + 4 * g, j = 16 * nt + tr;
-                L[C_P + 33 * i + j] = pp[g] + ((i == j) ? P.eps_coeff : 0.0);
-            }
-        }
-    }
-    bsync<NW>();
     return flags;
 }
 
