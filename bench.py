@@ -196,7 +196,7 @@ def main():
             "instances_flagged": flags,
             "summary_rows_gathered": int(gathered.shape[0]) if gathered is not None else 0,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # the CPU baseline is timed at N = 1 only
             try:
                 res["cpu_baseline"] = cpu_baseline(q0, zcom, args)
             except Exception as e:  # the baseline is reported, never required for the GPU number

@@ -28,6 +28,7 @@
 // The minimiser is unique (H is SPD), so this equals what qpOASES returns in the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "lmh_device.h"
 #include "../../include/lmh.h"
@@ -1879,7 +1880,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
 {
     int flags = 0, ph = 0;
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
-#define STAMP(i) do { if (dbg && LANE == 0) dbg[4000 + (i)] = (double)clock64(); } while (0)
+#define STAMP(i) do { if (dbg && LANE == 0) dbg[(wid ? 3950 : 4000) + (i)] = (double)clock64(); } while (0)   // wave 1 (diagnostic two-wave debug kernel): 3950..
     STAMP(0);
     const RefPrefetch pre = prefetch_refs(P, inst, t);
     if (wid == 0) phase_fk<R>(L, P.gcol + 228);
@@ -1983,10 +1984,9 @@ __device__ __forceinline__ void store_out(const double *L, double *out)
 // Controller::standStep + WBC for every instance (src/controller.cpp:48-154).
 // The plain kernel runs two waves per robot like the rollout; the debug kernel (intermediate dumps, stamps) keeps
 // the single-wave schedule.
-template <bool DEBUG, typename R>
-__global__ void __launch_bounds__(DEBUG ? 64 : LMH_ROLLOUT_THREADS) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
+template <bool DEBUG, typename R, int NW = (DEBUG ? 1 : 2)>
+__global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
 {
-    constexpr int NW = DEBUG ? 1 : 2;
     __shared__ double L[LDS_DOUBLES];
     const int inst = blockIdx.x;
     if (inst >= P.n_instances) return;
@@ -2365,7 +2365,9 @@ extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *c
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s)
 {
     // precision 1 (LMH_PRECISION_MIXED): model terms in fp32 arithmetic, references and QP in fp64; the debug kernel is fp64 only
-    if (debug) hipLaunchKernelGGL((lmh_eval_kernel<true, double>), dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
+    // LMH_DIAG_NW2=1: the debug kernel on the two-wave schedule (per-wave phase stamps; diagnostics only)
+    if (debug && getenv("LMH_DIAG_NW2")) hipLaunchKernelGGL((lmh_eval_kernel<true, double, 2>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
+    else if (debug) hipLaunchKernelGGL((lmh_eval_kernel<true, double>), dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
     else if (P->precision == 1) hipLaunchKernelGGL((lmh_eval_kernel<false, float>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
     else hipLaunchKernelGGL((lmh_eval_kernel<false, double>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
 }

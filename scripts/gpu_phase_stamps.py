@@ -62,3 +62,10 @@ for lo, hi in ((0, 8), (9, 16), (17, 24), (25, 31), (32, 32)):
     if m.sum():
         cone = (q[m, 3] - q[m, 2]).mean(); s1 = (d[m, 4023] - d[m, 4022]).mean()
         print("  |F| in [%2d,%2d]: %4d robots  mean eval cycles %7.0f  qp %7.0f  max %7.0f  | cone phase %6.0f  free-set solve #1 %6.0f  iters %.2f" % (lo, hi, m.sum(), tot[m].mean(), dur[m, 7].mean(), tot[m].max(), cone, s1, s[m, 1].mean()))
+
+if os.environ.get("LMH_DIAG_NW2"):
+    w1 = d[:, 3950:3960]
+    print("two-wave schedule, cycles from the start of the evaluation (wave 0 | wave 1) at the phase boundaries:")
+    for i, n in enumerate(['start', 'fk done', 'com_x done', '(dump)', '-', '-', 'tree phases done', 'refs done', 'qp done', 'outputs done']):
+        a0 = (st_[:, i] - st_[:, 0]).mean(); a1 = (w1[:, i] - st_[:, 0]).mean() if w1[:, i].any() else float('nan')
+        print("  %-18s %8.0f | %8.0f" % (n, a0, a1))
