@@ -22,7 +22,7 @@ stats = find("kt", "kernel_stats.csv")
 shutil.copy(stats, os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
 avg_ns = calls = None
 for row in csv.DictReader(open(stats)):
-    if row["Name"].startswith(KERNEL):
+    if KERNEL in row["Name"]:                                  # "void lmh_rollout_kernel<double>(...)"
         avg_ns, calls = float(row["AverageNs"]), int(row["Calls"])
 pmc = {}
 meta = {}
@@ -33,7 +33,7 @@ for sub in ("fetch", "write", "sq", "sq2", "grbm"):
         continue
     per = {}
     for row in csv.DictReader(open(f)):
-        if not row["Kernel_Name"].startswith(KERNEL):
+        if KERNEL not in row["Kernel_Name"]:
             continue
         meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
         per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
