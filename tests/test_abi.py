@@ -69,3 +69,32 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("# oracle-free", ""), f"{f} mentions the oracle"
+
+
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """include/lmh.h must be consumable by a C compiler (the boundary is a C ABI, not a C++ one): a C99 translation
+    unit that takes the address of every entry point compiles with -pedantic and links against liblmh_hip.so; it also
+    checks that sizeof(lmh_config) agrees with the ctypes mirror (capi.LmhConfig)."""
+    import subprocess
+    from linearmpchumanoid_amd import capi
+    names = declared_symbols()
+    src = tmp_path / "c_caller.c"
+    refs = "\n".join(f"    p[{i}] = (void (*)(void))&{n};" for i, n in enumerate(names))
+    src.write_text(f"""#include <stdio.h>
+#include "lmh.h"
+int main(void) {{
+    void (*p[{len(names)}])(void);
+    lmh_config cfg;
+{refs}
+    lmh_config_default(&cfg);
+    printf("%zu %d %g %g\\n", sizeof(lmh_config), cfg.precision, cfg.dt, cfg.eps_coeff);
+    return p[0] == 0;
+}}
+""")
+    exe = tmp_path / "c_caller"
+    libdir = os.path.dirname(capi.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-llmh_hip", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.check_output([str(exe)]).decode().split()       # lmh_config_default touches no device
+    assert int(out[0]) == C.sizeof(capi.LmhConfig)
+    assert int(out[1]) == capi.PRECISION_FP64 and float(out[2]) == 0.01 and float(out[3]) == 1e-8
