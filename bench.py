@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
+    ap.add_argument("--reset-every", type=int, default=23,
+                    help="restart the rollouts from the initial states after this many steps (the reference's closed loop, "
+                         "which integrates the controller's own acceleration, leaves its valid range ~0.5 s after a 0.3 m/s push; "
+                         "DESIGN.md 'Long runs'); the default equals warmup + steps of the default run, i.e. no restart there")
     ap.add_argument("--summary-out", default=None, help="write the gathered end-of-run summary (wire.write_summary format) to this path")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from rocprofv3 --pmc; default: the committed profiles/ summary when the workload matches it")
@@ -131,10 +135,12 @@ def main():
     th = args.horizon * args.dt
     cfg = default_config(dt=args.dt, time_horizon=th, z_com=zcom, warm_start=0 if args.cold else 1)
     ctl = BatchedController(count, cfg, device=local_rank)
-    total_ticks = (args.warmup + args.steps) * args.ticks
+    reset_every = max(1, args.reset_every)
+    total_ticks = min(args.warmup + args.steps, reset_every) * args.ticks
     ctl.set_refs_stance(total_ticks * args.dt + 1.0, 2)
     v = perturbed_velocities(first, count)
     state = ctl.new_state(q0, v, t=0.0)
+    state0 = state.clone()
     out, status = ctl.new_out(), ctl.new_status()
     log = torch.zeros((args.ticks, count, 36), dtype=torch.float64, device=ctl.device)
 
@@ -143,14 +149,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    done = 0
+
+    def step():
+        nonlocal done
+        if done and done % reset_every == 0:
+            state.copy_(state0)                               # device-to-device, inside the timed region when it happens
         ctl.rollout(state, args.ticks, out, status, log)
+        done += 1
+
+    for _ in range(args.warmup):
+        step()
     barrier()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        ctl.rollout(state, args.ticks, out, status, log)
+        step()
     ev1.record()
     barrier()
     t1 = time.perf_counter()
@@ -185,7 +200,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{B} NAO instances/GPU, balance task (IK posture + velocity perturbation), dt={args.dt}, LIPM-MPC horizon N={args.horizon}, WBC QP per evaluation, RK4 closed loop",
                        "instances_per_gpu": B, "ticks_per_step": args.ticks, "evaluations_per_tick": 4,
-                       "qp_start": "cold" if args.cold else "warm", "parallelism": f"instances sharded x{world}"},
+                       "qp_start": "cold" if args.cold else "warm", "parallelism": f"instances sharded x{world}",
+                       "rollout_restarts": (args.warmup + args.steps - 1) // reset_every},
             "evaluations_per_s": value * 4,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": profiled_traffic(args), "kernel": "lmh_rollout_kernel", "kernel_ms": kernel_ms,
