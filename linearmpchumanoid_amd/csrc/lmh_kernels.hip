@@ -117,7 +117,9 @@ enum {
     P_TAB = 2286,     // theta offsets (24)
     P_POLY = 2310,    // foot polynomials: rF[3][8] | lF[3][8] | counts (6, stored as doubles)
     P_MPCK = 2366,    // MPC record K | Px0 | Px1 (3 (N+1) doubles) when N <= MPC_LDS_MAXN
-    P_END = 2504,
+    P_KI = 2504,      // K_f^-1 of the warm-start free set (2 x 6 x 6), prepared by the helper wave during the kinematics
+    P_KF = 2576,      // [0] free set published by the last cone solve | [1] free set P_KI belongs to | [2] 1 = valid, 2 = singular, 0 = none
+    P_END = 2580,
     // ---- scratch, phase A1 (kinematics + Newton-Euler)
     S0 = P_END,
     A_LC = S0 + 0,    // 28 x 12 local transforms (dead after FK)
@@ -1386,12 +1388,14 @@ __device__ __forceinline__ void ldl6_pair_back(double (&b)[6], int l16, const do
         ldl6_pair_back<J - 1>(b, l16, Lrow);
     }
 }
-__device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P, unsigned F, double *s_out, int *flags)
+// K_f^-1 of both feet for the free set F into Kdst (2 x 36); `scr` = 160 doubles of scratch.  Returns non-zero
+// (wave-uniform) when a foot with free coefficients has a singular K_f.
+__device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst, double *scr)
 {
     const int lane = LANE, l16 = lane & 15, row = lane >> 4;
     const unsigned FR = F & 0xFFFFu, FL = F >> 16;
     const bool useR = FR != 0u, useL = FL != 0u;
-    double *K = L + C_LS, *Ki = L + C_LS + 72, *Yv = L + C_LS + 144, *Ls = L + C_LS + 200;
+    double *K = scr, *Ki = Kdst, *Ls = scr + 72;
     WSYNC();
     {   // K_f = G diag(free_f) G' for both feet as ONE 16 x 16 x 16 matrix-core product: row block f of A carries foot f's
         // mask, so the two diagonal 6 x 6 blocks of the tile are K_R and K_L (the off-diagonal blocks are not used)
@@ -1431,8 +1435,19 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
             for (int c = 0; c < 6; c++) Ki[36 * row + 6 * l16 + c] = on ? bb[c] : 0.0;       // K_f^-1 (symmetric); 0 for a foot without force
         }
     }
-    const unsigned badm = (unsigned)__ballot(bad != 0);
-    if (badm != 0u) return 0;                                      // wave-uniform: some K_f is singular
+    WSYNC();
+    return (__ballot(bad != 0) != 0ull) ? 1 : 0;
+}
+
+// `have_ki`: 1 = K_f^-1 of this F already sits in L[P_KI] (helper wave), 2 = known singular, 0 = compute here.
+__device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P, unsigned F, int have_ki, double *s_out, int *flags)
+{
+    const int lane = LANE;
+    const unsigned FR = F & 0xFFFFu, FL = F >> 16;
+    const bool useR = FR != 0u, useL = FL != 0u;
+    double *Ki = (have_ki == 1) ? L + P_KI : L + C_LS + 72, *Yv = L + C_LS + 144, *Ls = L + C_LS + 200;
+    if (have_ki == 2) return 0;
+    if (have_ki == 0 && kinv_compute(L, F, L + C_LS + 72, L + C_LS + 240)) return 0;     // wave-uniform: some K_f is singular
     WSYNC();
     {   // (W + eps K^-1) w = h on the rows of the feet that carry force
         double a[12], b[1];
@@ -1552,7 +1567,8 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         double zj;
         if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
         double sj;
-        if (!lh && cone_pushthrough(L, P, F, &sj, &flags)) {       // 12 x 12 route: coefficients and multipliers from one vector
+        const int have_ki = __builtin_amdgcn_readfirstlane((F == (unsigned)L[P_KF + 1]) ? (int)L[P_KF + 2] : 0);   // prepared by the helper wave for the warm-start set
+        if (!lh && cone_pushthrough(L, P, F, have_ki, &sj, &flags)) {   // 12 x 12 route: coefficients and multipliers from one vector
             const bool fr = (lane < 32) && ((F >> lane) & 1u);
             zj = fr ? sj : 0.0;
             lj = (lane < 32 && !fr) ? -P.eps_coeff * sj : 0.0;
@@ -1797,7 +1813,8 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
 {
     const int lane = LANE;
     int flags = (P.w_com_ang == 0.0) ? qp_setup<15, NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
-    if (NW == 2 && wid != 0) return 0;                             // the active-set iteration and the recovery are sequential: wave 0
+    if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }            // the active-set iteration and the recovery are sequential: wave 0;
+                                                                   // the helper waits for the free set it will prepare K^-1 for
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
     // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
     unsigned forced = 0u;
@@ -1809,6 +1826,8 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     WSYNC();
     *Fmask_io = F;
     *iters_out = it;
+    if (lane == 0) L[P_KF] = (double)F;                            // published for the helper wave (next evaluation's warm start)
+    bsync<NW>();
     if (dbgp && LANE == 0) dbgp[4013] = (double)clock64();
     // ---- recover w = G c, lam = -Si (Jb' w - d), a = -(Y_g + Y_M lam)
     if (lane < 12) {
@@ -1883,6 +1902,19 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
 #define STAMP(i) do { if (dbg && LANE == 0) dbg[(wid ? 3950 : 4000) + (i)] = (double)clock64(); } while (0)   // wave 1 (diagnostic two-wave debug kernel): 3950..
     STAMP(0);
     const RefPrefetch pre = prefetch_refs(P, inst, t);
+    if (NW == 2 && wid == 1) {
+        // while wave 0 runs the forward kinematics: K_f^-1 of the free set the cone solve will start from (same rule as
+        // phase_qp: previous active set minus the coefficients of feet out of support); scratch: the CRBA parking area
+        unsigned forced = 0u;
+        if (pre.ph == LMH_PHASE_LEFT || pre.ph == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;
+        if (pre.ph == LMH_PHASE_RIGHT || pre.ph == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
+        const unsigned Fpub = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)L[P_KF]);
+        const unsigned F0 = (P.warm_start ? Fpub : 0xFFFFFFFFu) & ~forced;
+        int st = 0;
+        if (F0 != 0xFFFFFFFFu) st = kinv_compute(L, F0, L + P_KI, L + A_XR) ? 2 : 1;     // all free: the constant table is used instead
+        if (LANE == 0) { L[P_KF + 1] = (double)F0; L[P_KF + 2] = (double)st; }
+    }
+    if (NW == 1 && LANE == 0) L[P_KF + 2] = 0.0;                   // single-wave schedule: nothing prepared
     if (wid == 0) phase_fk<R>(L, P.gcol + 228);
     bsync<NW>();
     STAMP(1);
@@ -2000,6 +2032,7 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, doubl
         for (int e = LANE; e < 91; e += 64) L[P_Q + e] = st[e];    // q | v | v_prev | t
         F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
         F = P.warm_start ? ~F : 0xFFFFFFFFu;                       // status keeps the ACTIVE mask
+        if (LANE == 0) L[P_KF] = (double)F;
         WSYNC();
     }
     bsync<NW>();
@@ -2040,6 +2073,7 @@ lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, 
         if (lane < 30) L[P_VP + lane] = st[60 + lane];
         F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
         F = P.warm_start ? ~F : 0xFFFFFFFFu;
+        if (lane == 0) L[P_KF] = (double)F;
     }
     bsync<2>();
     int k = 0, iters = 0, flags = 0, itmax = 0;
