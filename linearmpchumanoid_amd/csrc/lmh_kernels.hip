@@ -119,7 +119,10 @@ enum {
     P_MPCK = 2366,    // MPC record K | Px0 | Px1 (3 (N+1) doubles) when N <= MPC_LDS_MAXN
     P_KI = 2504,      // K_f^-1 of the warm-start free set (2 x 6 x 6), prepared by the helper wave during the kinematics
     P_KF = 2576,      // [0] free set published by the last cone solve | [1] free set P_KI belongs to | [2] 1 = valid, 2 = singular, 0 = none
-    P_END = 2580,
+    P_PRE = 2580,     // per-evaluation references that depend on the clock only, prepared ahead of the kinematics:
+                      // [0..1] sum K_i zmp_x/y[k+i] | [2..3] sum K_i Px0_i, sum K_i Px1_i (per launch) | [4..21] foot polynomial
+                      // position / velocity / acceleration, 3 per (foot, axis)
+    P_END = 2602,
     // ---- scratch, phase A1 (kinematics + Newton-Euler)
     S0 = P_END,
     A_LC = S0 + 0,    // 28 x 12 local transforms (dead after FK)
@@ -1018,6 +1021,60 @@ __device__ __forceinline__ RefPrefetch prefetch_refs(const LmhDevParams &P, int 
     return r;
 }
 
+// References that depend on the clock only (preview window of the ZMP, foot polynomials): evaluated before / beside the
+// kinematics (NW = 2: by the helper wave while wave 0 runs the forward kinematics).
+__device__ __forceinline__ void refs_prepare(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre)
+{
+    const int lane = LANE;
+    const int N = P.horizon, k = pre.k;
+    {
+        const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
+        double sx = 0.0, sy = 0.0;
+        for (int i = lane; i <= N; i += 64) {
+            double zxv = pre.zx, zyv = pre.zy;
+            if (i >= 64) {                                         // only N = 64 reaches a second round
+                int kk = k + i;
+                kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
+                zxv = P.zmpx[kk]; zyv = P.zmpy[kk];
+            }
+            const double K = (N <= MPC_LDS_MAXN) ? L[P_MPCK + i] : mp[i];
+            sx += K * zxv; sy += K * zyv;
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy);
+        if (lane == 0) { L[P_PRE] = sx; L[P_PRE + 1] = sy; }
+    }
+    if (lane >= 16 && lane < 22) {                                 // polyval / polyder of the foot references (controller.cpp:355-386)
+        const int ft = (lane - 16) / 3, ax = (lane - 16) % 3;
+        double co[8];
+        int n;
+        double tl = t;
+        if (P.n_seg > 0) {                                         // walking extension: segment of preview index k
+            const int kk = (k < 0) ? 0 : (k >= P.n_samples ? P.n_samples - 1 : k);
+            const double *sg = P.segs + (size_t)LMH_SEG_STRIDE * P.seg_of_sample[kk];
+            const double sc = (ax == 0 && P.xscale) ? P.xscale[inst] : 1.0;
+            tl = t - sg[0];
+#pragma unroll
+            for (int i = 0; i < 8; i++) co[i] = sg[1 + 24 * ft + 8 * ax + i] * sc;
+            n = 8;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) co[i] = L[P_POLY + 24 * ft + 8 * ax + i];
+            n = (int)L[P_POLY + 48 + 3 * ft + ax];
+        }
+        double pv = 0, xp = 1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i < n) { pv += co[i] * xp; xp *= tl; }
+        double vv = 0; xp = 1;
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (i < n - 1) { vv += ((i + 1) * co[i + 1]) * xp; xp *= tl; }
+        double av = 0; xp = 1;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i < n - 2) { av += ((i + 1) * ((i + 2) * co[i + 2])) * xp; xp *= tl; }
+        double *pr = L + P_PRE + 4 + 3 * (3 * ft + ax);
+        pr[0] = pv; pr[1] = vv; pr[2] = av;
+    }
+}
+
 // The references form two independent chains: (A) AG, AGpqp -> momentum -> MPC -> PDMomentumAcc needs the mass
 // matrix; (B) foot velocities, PDJointsAcc -> PDFeetAcc needs the Jacobian.  NW = 1 interleaves them step by
 // step in one wave; NW = 2 gives chain A to wave 1 and chain B to wave 0 (the caller joins them).
@@ -1090,23 +1147,12 @@ __device__ __forceinline__ int refs_mpc(double *L, const LmhDevParams &P, int in
     const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
     const double zcom = mp[3 * (N + 1)];
     {
+        // K (Px x_k - z) = x (sum K Px0) + xdot (sum K Px1) - sum K z: the three sums do not depend on the robot state and
+        // are prepared early (refs_prepare / load_common)
         const double cxp = L[P_COM], cyp = L[P_COM + 1], vxp = L[P_COMV], vyp = L[P_COMV + 1];
-        const double xs = pre.xs;
-        double sx = 0.0, sy = 0.0;
-        for (int i = lane; i <= N; i += 64) {
-            double zxv = pre.zx, zyv = pre.zy;
-            if (i >= 64) {                                         // only N = 64 reaches a second round
-                int kk = k + i;
-                kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
-                zxv = P.zmpx[kk]; zyv = P.zmpy[kk];
-            }
-            double K, px0, px1;
-            if (N <= MPC_LDS_MAXN) { K = L[P_MPCK + i]; px0 = L[P_MPCK + (N + 1) + i]; px1 = L[P_MPCK + 2 * (N + 1) + i]; }   // on-chip copy
-            else { K = mp[i]; px0 = mp[(N + 1) + i]; px1 = mp[2 * (N + 1) + i]; }
-            sx += K * ((px0 * cxp + px1 * vxp) - zxv * xs);
-            sy += K * ((px0 * cyp + px1 * vyp) - zyv);
-        }
-        sx = wave_sum(sx); sy = wave_sum(sy);
+        const double kp0 = L[P_PRE + 2], kp1 = L[P_PRE + 3];
+        const double sx = (kp0 * cxp + kp1 * vxp) - pre.xs * L[P_PRE];
+        const double sy = (kp0 * cyp + kp1 * vyp) - L[P_PRE + 1];
         const double ux = -sx, uy = -sy;
         if (lane == 0) {
             L[P_MPC + 0] = ux; L[P_MPC + 1] = uy;
@@ -1154,31 +1200,8 @@ __device__ __forceinline__ void refs_pd_feet(double *L, const LmhDevParams &P, i
     }
     if (lane >= 16 && lane < 22) {                                 // position part, polynomials (polyval/polyder)
         const int ft = (lane - 16) / 3, ax = (lane - 16) % 3;
-        double co[8];
-        int n;
-        double tl = t;
-        if (P.n_seg > 0) {                                         // walking extension: segment of preview index k
-            const int kk = (k < 0) ? 0 : (k >= P.n_samples ? P.n_samples - 1 : k);
-            const double *sg = P.segs + (size_t)LMH_SEG_STRIDE * P.seg_of_sample[kk];
-            const double sc = (ax == 0 && P.xscale) ? P.xscale[inst] : 1.0;
-            tl = t - sg[0];
-#pragma unroll
-            for (int i = 0; i < 8; i++) co[i] = sg[1 + 24 * ft + 8 * ax + i] * sc;
-            n = 8;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) co[i] = L[P_POLY + 24 * ft + 8 * ax + i];
-            n = (int)L[P_POLY + 48 + 3 * ft + ax];
-        }
-        double pv = 0, xp = 1;
-#pragma unroll
-        for (int i = 0; i < 8; i++) if (i < n) { pv += co[i] * xp; xp *= tl; }
-        double vv = 0; xp = 1;
-#pragma unroll
-        for (int i = 0; i < 7; i++) if (i < n - 1) { vv += ((i + 1) * co[i + 1]) * xp; xp *= tl; }
-        double av = 0; xp = 1;
-#pragma unroll
-        for (int i = 0; i < 6; i++) if (i < n - 2) { av += ((i + 1) * ((i + 2) * co[i + 2])) * xp; xp *= tl; }
+        const double *pr = L + P_PRE + 4 + 3 * (3 * ft + ax);     // refs_prepare
+        const double pv = pr[0], vv = pr[1], av = pr[2];
         const double pe = pv - L[P_TB + 12 * (1 + ft) + 4 * ax + 3];
         const double ve = vv - L[P_VFOOT + 6 * ft + 3 + ax];
         L[P_FREF + 6 * ft + 3 + ax] = P.kp_feet * pe + P.kd_feet * ve + av;
@@ -1913,8 +1936,13 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         int st = 0;
         if (F0 != 0xFFFFFFFFu) st = kinv_compute(L, F0, L + P_KI, L + A_XR) ? 2 : 1;     // all free: the constant table is used instead
         if (LANE == 0) { L[P_KF + 1] = (double)F0; L[P_KF + 2] = (double)st; }
+        refs_prepare(L, P, inst, t, pre);
     }
-    if (NW == 1 && LANE == 0) L[P_KF + 2] = 0.0;                   // single-wave schedule: nothing prepared
+    if constexpr (NW == 1) {                                       // single-wave schedule: no K^-1 prepared; references first
+        if (LANE == 0) L[P_KF + 2] = 0.0;
+        refs_prepare(L, P, inst, t, pre);
+        WSYNC();
+    }
     if (wid == 0) phase_fk<R>(L, P.gcol + 228);
     bsync<NW>();
     STAMP(1);
@@ -1995,9 +2023,16 @@ __device__ __forceinline__ void load_common(double *L, const LmhDevParams &P, in
         L[P_POLY + LANE] = (double)n;
     }
     load_tables(L);
-    if (P.horizon <= MPC_LDS_MAXN) {                               // gain row + Px columns stay on chip for the launch
+    {
         const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
-        for (int e = LANE; e < 3 * (P.horizon + 1); e += 64) L[P_MPCK + e] = mp[e];
+        const int N = P.horizon;
+        if (N <= MPC_LDS_MAXN) {                                   // gain row + Px columns stay on chip for the launch
+            for (int e = LANE; e < 3 * (N + 1); e += 64) L[P_MPCK + e] = mp[e];
+        }
+        double s0 = 0.0, s1 = 0.0;                                 // sum K Px0, sum K Px1 (refs_mpc)
+        for (int i = LANE; i <= N; i += 64) { s0 += mp[i] * mp[(N + 1) + i]; s1 += mp[i] * mp[2 * (N + 1) + i]; }
+        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        if (LANE == 0) { L[P_PRE + 2] = s0; L[P_PRE + 3] = s1; }
     }
     WSYNC();
 }
