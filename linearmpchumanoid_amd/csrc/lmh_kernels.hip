@@ -1606,6 +1606,7 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
             const double tolc = 1e-10 * (1.0 + cmax);
             const bool isbad = mine && ((inF && zj < -tolc) || (!inF && lj < -toll));
             const unsigned bad = (unsigned)__ballot(isbad);
+            if (dbgp && lane == 0 && it <= 12) { dbgp[3960 + it] = (double)F; dbgp[3975 + it] = (double)bad; }   // round trace (diagnostics)
             cj = zj;
             if (bad == 0u) break;
             if (it >= BPP_MAX) { lh = true; F = 0u; cj = 0.0; continue; }    // next solve: F empty, lam = -qv
