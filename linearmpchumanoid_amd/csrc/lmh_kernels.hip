@@ -2114,6 +2114,9 @@ lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, 
     bsync<2>();
     int k = 0, iters = 0, flags = 0, itmax = 0;
     const double dt = P.dt;
+#ifdef LMH_SUBSTAMPS
+    const long long t_launch = clock64();
+#endif
     // the leading wave carries the critical path: it wins issue arbitration against the helper wave of the robot it
     // shares the SIMD with (+2.7 % measured; the reverse assignment gains nothing)
     if (wid == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
@@ -2169,6 +2172,9 @@ lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, 
     if (wid == 0) {
         WSYNC();
         store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
+#ifdef LMH_SUBSTAMPS
+        if (lane == 0) out[(size_t)LMH_OUT_STRIDE * inst + 78] = (double)(clock64() - t_launch);   // diagnostic build: this robot's cycles in the launch (pad slot)
+#endif
         if (lane < 60) st[lane] = x;
         if (lane < 30) st[60 + lane] = L[P_VP + lane];
         if (lane == 0) {

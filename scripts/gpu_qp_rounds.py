@@ -16,5 +16,7 @@ for step in range(23):
     e0.record(); ctl.rollout(st, 10, out, status); e1.record(); torch.cuda.synchronize()
     it = status.cpu().numpy()[:, 1]
     h = np.bincount(np.minimum(it, 12), minlength=13)
+    cyc = out.cpu().numpy()[:, 78]
+    extra = ("  robot cycles mean %.0f p50 %.0f p99 %.0f max %.0f (max/mean %.3f)" % (cyc.mean(), np.median(cyc), np.percentile(cyc, 99), cyc.max(), cyc.max() / cyc.mean())) if cyc.max() > 0 else ""
     print("step %2d  %.3f ms  max rounds %2d  robots with rounds [1,2,3,4,5-10,>10]: %4d %4d %4d %4d %4d %4d" % (
-        step, e0.elapsed_time(e1), it.max(), h[1], h[2], h[3], h[4], h[5:11].sum(), h[11:].sum()))
+        step, e0.elapsed_time(e1), it.max(), h[1], h[2], h[3], h[4], h[5:11].sum(), h[11:].sum()) + extra)
