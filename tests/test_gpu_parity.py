@@ -473,6 +473,45 @@ def test_randomised_walking_config4_ingredients(cfg2):
             assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
 
 
+def test_cone_qp_kkt_at_scale(cfg2):
+    """Optimality of the contact-force QP, independent of the oracle: for 1024 strongly perturbed states in each
+    support phase the kernel's coefficients c must satisfy the KKT conditions of
+    min 1/2 c'Pc - q'c, c >= 0 (forced coefficients 0) with P = G'WG + eps I and q = G'h taken from the debug record:
+    c >= 0, (Pc - q)_j = 0 where c_j > 0, (Pc - q)_j >= 0 where c_j = 0.  P is strictly convex, so KKT <=> the
+    unique minimiser.  This covers the push-through route, the general free-set route and the fall-backs."""
+    from linearmpchumanoid_amd.controller import unpack_debug
+    B = 1024
+    v = perturbed_velocities(B, seed=777) * 2.0                   # 0.6 m/s pushes: most robots have active bounds
+    worst = 0.0
+    n_active = 0
+    for ph in (0, 1, 2):
+        ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=0)
+        n = 2500
+        ctl.set_refs(np.zeros(n), np.zeros(n), np.full(n, ph, dtype=np.uint8))
+        st = ctl.new_state(cfg2["q0"], v, t=0.0)
+        out, status, dbg = ctl.stand_step(st, debug=True)
+        torch.cuda.synchronize()
+        dbg, status = dbg.cpu().numpy(), status.cpu().numpy()
+        assert (status[:, 2] == 0).all()
+        forced = np.zeros(32, dtype=bool)
+        if ph == 2: forced[:16] = True                            # left support: the right foot carries nothing
+        if ph == 1: forced[16:] = True
+        for i in range(B):
+            d = unpack_debug(dbg[i])
+            Pm, q, c = d["P"], d["qv"], d["c"]
+            lam = Pm @ c - q
+            scale = 1.0 + np.abs(q).max()
+            assert c.min() >= -1e-9 * (1.0 + c.max()), (ph, i, c.min())
+            assert np.abs(c[forced]).max(initial=0.0) == 0.0
+            free = (c > 1e-9 * (1.0 + c.max())) & ~forced
+            at0 = ~free & ~forced
+            assert np.abs(lam[free]).max(initial=0.0) < 1e-9 * scale, (ph, i)
+            assert lam[at0].min(initial=0.0) > -1e-9 * scale, (ph, i, lam[at0].min(initial=0.0))
+            worst = max(worst, np.abs(lam[free]).max(initial=0.0) / scale)
+            n_active += int(at0.sum() > 0)
+    assert n_active > B                                            # the bounds really are active in a large share of the cases
+
+
 def test_two_wave_schedule_is_deterministic_and_equals_the_single_wave_schedule(cfg2):
     """The plain evaluation kernel and the rollout run two cooperating waves per robot (joined at workgroup
     barriers); the debug kernel runs the same arithmetic on one wave.  Every LDS entry is produced by the same
