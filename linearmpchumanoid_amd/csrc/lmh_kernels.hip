@@ -816,20 +816,33 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
 // recursion never round-trips it through LDS; all five chains advance one level per pass.
 
 // rows of the 6x6 body inertia [Ibar, [h]x; -[h]x, m 1] (Dynamics.cpp:4-13): entries (r, 3cb..3cb+2)
+// Which three entries of the 6x6 body inertia a lane owns depends on its (row r, column block cb) only, so the
+// selection is derived ONCE per pass as (record index, sign) pairs: out[k] = sg[k] * mo[idx[k]] -- three loads and
+// three multiplies per use instead of a dozen selects.
 template <typename R>
-__device__ __forceinline__ void body_row3(const LV<R> mo, int r, int cb, R out[3])
+struct BodyRowSel { int i0, i1, i2; R s0, s1, s2; };
+template <typename R>
+__device__ __forceinline__ BodyRowSel<R> body_row_sel(int r, int cb)
 {
     const bool up = r < 3;
     const int a = up ? r : r - 3;
-    const R hx = mo[9], hy = mo[10], hz = mo[11], m = mo[12];
-    const R c0 = (a == 0) ? 0.0 : (a == 1) ? hz : -hy;       // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0]
-    const R c1 = (a == 0) ? -hz : (a == 1) ? 0.0 : hx;
-    const R c2 = (a == 0) ? hy : (a == 1) ? -hx : 0.0;
-    const R i0 = mo[3 * a], i1 = mo[3 * a + 1], i2 = mo[3 * a + 2];
     const bool diag = (up == (cb == 0));                           // (up, cb=0): Ibar row; (down, cb=1): m e_a
-    out[0] = diag ? (up ? i0 : ((a == 0) ? m : 0.0)) : (up ? c0 : -c0);
-    out[1] = diag ? (up ? i1 : ((a == 1) ? m : 0.0)) : (up ? c1 : -c1);
-    out[2] = diag ? (up ? i2 : ((a == 2) ? m : 0.0)) : (up ? c2 : -c2);
+    BodyRowSel<R> q;
+    if (diag && up) { q.i0 = 3 * a; q.i1 = 3 * a + 1; q.i2 = 3 * a + 2; q.s0 = 1; q.s1 = 1; q.s2 = 1; }
+    else if (diag) { q.i0 = 12; q.i1 = 12; q.i2 = 12; q.s0 = (a == 0) ? 1 : 0; q.s1 = (a == 1) ? 1 : 0; q.s2 = (a == 2) ? 1 : 0; }
+    else {
+        // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0] with h = mo[9..11]; the lower-left block is its negative
+        const R sg = up ? (R)1 : (R)-1;
+        q.i0 = (a == 1) ? 11 : 10; q.s0 = (a == 0) ? (R)0 : (a == 1) ? sg : -sg;
+        q.i1 = (a == 0) ? 11 : 9;  q.s1 = (a == 1) ? (R)0 : (a == 0) ? -sg : sg;
+        q.i2 = (a == 0) ? 10 : 9;  q.s2 = (a == 2) ? (R)0 : (a == 0) ? sg : -sg;
+    }
+    return q;
+}
+template <typename R>
+__device__ __forceinline__ void body_row3(const LV<R> mo, const BodyRowSel<R> &q, R out[3])
+{
+    out[0] = q.s0 * (R)mo[q.i0]; out[1] = q.s1 * (R)mo[q.i1]; out[2] = q.s2 * (R)mo[q.i2];
 }
 template <typename R>
 __device__ __forceinline__ void crba_z(const LV<R> L, int i, int slot, int r, int cb, R out[3])   // (X_i' Y)(r, 3cb..)
@@ -852,13 +865,14 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
     const int ch = lane / 12, t = lane % 12, r = t >> 1, cb = t & 1;
     const int nact = (ch < 2) ? 6 : (ch < 4) ? 5 : 2;             // actuated frames of this lane's chain
     const int cbase = f_chain_base(ch < 5 ? ch : 4);
+    const BodyRowSel<R> bsel = body_row_sel<R>(r, cb);
     R ic[3] = {0.0, 0.0, 0.0};                               // Ic_i[r][3cb .. 3cb+2] of the frame being folded
 #pragma unroll
     for (int dl = 6; dl >= 1; dl--) {                              // chain depth of the frames folded into their parents
         const bool on = (lane < 60) && (dl <= nact);
         const int i = cbase + (on ? dl - 1 : 0);                   // safe frame index for the idle lanes
         R leaf[3];
-        body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, r, cb, leaf);
+        body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, bsel, leaf);
         if (dl == nact) { ic[0] = leaf[0]; ic[1] = leaf[1]; ic[2] = leaf[2]; }   // leaf: Ic = I (Dynamics.cpp:72)
         if (on && cb == 0) L[A_FB + 6 * (f_act(i) - 1) + r] = ic[2];             // f = Ic_i S for the joint columns
         const R p0 = dpp_row<0xB1>(ic[0]), p1 = dpp_row<0xB1>(ic[1]), p2 = dpp_row<0xB1>(ic[2]);   // partner lane ^ 1 (cb ^ 1)
@@ -880,7 +894,7 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
         {
             R z[3], bp3[3];
             crba_z(L, i, (lane < 60) ? ch : 0, r, cb, z);
-            body_row3(L + P_MODEL + LMH_BODY_STRIDE * ((i > 0) ? i - 1 : 0), r, cb, bp3);
+            body_row3(L + P_MODEL + LMH_BODY_STRIDE * ((i > 0) ? i - 1 : 0), bsel, bp3);
             if (dl >= 2) {                                         // Ic[parent] = Ic[parent] + X' Ic X (Dynamics.cpp:82), parent = i-1
                 if (on) { ic[0] = bp3[0] + z[0]; ic[1] = bp3[1] + z[1]; ic[2] = bp3[2] + z[2]; }
             } else if (on) {                                       // depth 1: park the contribution to the base
@@ -894,7 +908,7 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
     SUBSTAMP(10);
     if (lane < 12) {                                               // Ic0 = I0 + head + LA + RA + LL + RL (Dynamics.cpp:80-82 order)
         R acc[3];
-        body_row3(L + P_MODEL, r, cb, acc);
+        body_row3(L + P_MODEL, bsel, acc);
 #pragma unroll
         for (int sl = 0; sl < 5; sl++) {
             const LV<R> o = L + A_XR + 36 * sl + 6 * r + 3 * cb;
@@ -1963,8 +1977,9 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         STAMP(5);
         phase_jacobian<R>(L);
     } else {
-        if (wid == 0) { phase_newton_euler<R>(L); phase_jacobian<R>(L); }    // LDS regions of the three are disjoint
+        if (wid == 0) { phase_newton_euler<R>(L); STAMP(4); phase_jacobian<R>(L); }    // LDS regions of the three are disjoint
         else phase_crba<R>(L);
+        STAMP(5);                                                  // per wave: end of its share of the tree phases
     }
     bsync<NW>();
     STAMP(6);

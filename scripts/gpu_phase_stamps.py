@@ -66,6 +66,6 @@ for lo, hi in ((0, 8), (9, 16), (17, 24), (25, 31), (32, 32)):
 if os.environ.get("LMH_DIAG_NW2"):
     w1 = d[:, 3950:3960]
     print("two-wave schedule, cycles from the start of the evaluation (wave 0 | wave 1) at the phase boundaries:")
-    for i, n in enumerate(['start', 'fk done', 'com_x done', '(dump)', '-', '-', 'tree phases done', 'refs done', 'qp done', 'outputs done']):
+    for i, n in enumerate(['start', 'fk done', 'com_x done', '(dump)', 'NE done (w0)', 'own tree share done', 'tree phases joined', 'refs done', 'qp done', 'outputs done']):
         a0 = (st_[:, i] - st_[:, 0]).mean(); a1 = (w1[:, i] - st_[:, 0]).mean() if w1[:, i].any() else float('nan')
         print("  %-18s %8.0f | %8.0f" % (n, a0, a1))
