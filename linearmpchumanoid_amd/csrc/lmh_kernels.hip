@@ -715,6 +715,8 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
         const int adj = (c == 0) ? 0 : (c == 1) ? 1 : 2;          // act(frame) = frame - adj on this chain (Robot.cpp:172)
         const int abase = which ? A_ACC0 : A_ACCG;
         const bool live = lane < 60;
+        const int cs_ix = (k == 0) ? 1 : (k == 1) ? 0 : (k == 3) ? 4 : (k == 4) ? 3 : 0;       // crm(v) S component of this lane
+        const R cs_sg = (k == 0 || k == 3) ? (R)1 : (k == 1 || k == 4) ? (R)-1 : (R)0;
 #pragma unroll
         for (int d = 0; d < 8; d++) {
             WSYNC();
@@ -732,7 +734,7 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
             const LV<R> vi = L + A_VEL + 6 * ia;
             const R qda = L[P_VHS + 5 + ia - adj];
             // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
-            const R cs = (k == 0) ? vi[1] : (k == 1) ? -vi[0] : (k == 3) ? vi[4] : (k == 4) ? -vi[3] : 0.0;
+            const R cs = cs_sg * (R)vi[cs_ix];                     // one load: (index, sign) derived once per pass
             aval += (e < nact) ? cs * qda : 0.0;
             if (live && which == 0 && d < nact) L[A_VEL + 6 * iv + k] = vval;
             if (live && e >= 0 && e < nacc) L[abase + 6 * ia + k] = aval;
@@ -882,10 +884,13 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
         {
             const LV<R> E = L + A_XE + 9 * i, Bm = L + A_XB + 9 * i;
             const R l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
+            // second operand: row c of E (cb = 1) or column c of B (cb = 0) -- selected by ADDRESS (base, stride), three loads
+            const LV<R> Xs = L + (cb ? A_XE : A_XB) + 9 * i;
+            const int xst = cb ? 1 : 3, xcs = cb ? 3 : 1;
             R y[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const R x0 = cb ? E[3 * c] : Bm[c], x1 = cb ? E[3 * c + 1] : Bm[3 + c], x2 = cb ? E[3 * c + 2] : Bm[6 + c];
+                const R x0 = Xs[xcs * c], x1 = Xs[xcs * c + xst], x2 = Xs[xcs * c + 2 * xst];
                 y[c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + hi[0] * x0 + hi[1] * x1 + hi[2] * x2;
             }
             if (on) { LV<R> yo = L + A_YT + 36 * ch + 6 * r + 3 * cb; yo[0] = y[0]; yo[1] = y[1]; yo[2] = y[2]; }
