@@ -852,8 +852,11 @@ __device__ __forceinline__ void crba_z(const LV<R> L, int i, int slot, int r, in
     const LV<R> E = L + A_XE + 9 * i, Bm = L + A_XB + 9 * i, Y = L + A_YT + 36 * slot + 3 * cb;
     const bool up = r < 3;
     const int a = up ? r : r - 3;
-    const R lo0 = up ? E[3 * a] : 0.0, lo1 = up ? E[3 * a + 1] : 0.0, lo2 = up ? E[3 * a + 2] : 0.0;
-    const R hi0 = up ? Bm[a] : E[3 * a], hi1 = up ? Bm[3 + a] : E[3 * a + 1], hi2 = up ? Bm[6 + a] : E[3 * a + 2];
+    const R mu = up ? (R)1 : (R)0;                                // the upper rows also see E' on the first three rows of Y
+    const R lo0 = mu * (R)E[3 * a], lo1 = mu * (R)E[3 * a + 1], lo2 = mu * (R)E[3 * a + 2];
+    const LV<R> H = up ? Bm + a : E + 3 * a;                       // column a of B (stride 3) | row a of E: picked by address
+    const int hst = up ? 3 : 1;
+    const R hi0 = H[0], hi1 = H[hst], hi2 = H[2 * hst];
 #pragma unroll
     for (int c = 0; c < 3; c++)
         out[c] = lo0 * Y[c] + lo1 * Y[6 + c] + lo2 * Y[12 + c] + hi0 * Y[18 + c] + hi1 * Y[24 + c] + hi2 * Y[30 + c];
