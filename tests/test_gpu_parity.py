@@ -473,6 +473,39 @@ def test_randomised_walking_config4_ingredients(cfg2):
             assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
 
 
+def test_arbitrary_warm_start_sets_reach_the_same_minimiser(cfg2):
+    """The warm start is only a starting point: whatever active set the status word carries (a foot with a single
+    free vertex -> singular K_f, so the helper wave's K^-1 is refused and the general free-set solve with the lazily
+    formed cone Hessian runs; nothing free; everything free; random sets), the evaluation must land on the unique
+    minimiser, i.e. on the cold-start result and on the oracle."""
+    B = 64
+    v = perturbed_velocities(B, seed=909) * 1.5
+    ctl_cold = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=0)
+    ctl_cold.set_refs_stance(2.0, 2)
+    st = ctl_cold.new_state(cfg2["q0"], v, t=0.0)
+    ref, sref = ctl_cold.stand_step(st)
+    torch.cuda.synchronize()
+    ref = ref.cpu().numpy()
+    rng = np.random.default_rng(5)
+    masks = [0x0000FFF0, 0xFFFFFFFF, 0x00000000, 0xFFF0FFF0, 0x0FFF0001] + [int(x) for x in rng.integers(0, 2 ** 32, 6, dtype=np.uint64)]
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=1)
+    ctl.set_refs_stance(2.0, 2)
+    for m in masks:                                               # status[3] holds the ACTIVE mask (1 = coefficient at its bound)
+        status = ctl.new_status()
+        status[:, 3] = int(np.array(m, dtype=np.uint32).astype(np.int32))
+        for debug in (False, True):                               # two-wave plain kernel and single-wave debug kernel
+            st = ctl.new_state(cfg2["q0"], v, t=0.0)
+            res = ctl.stand_step(st, status=status.clone(), debug=debug)
+            torch.cuda.synchronize()
+            out, sts = res[0].cpu().numpy(), res[1].cpu().numpy()
+            assert (sts[:, 2] == 0).all(), hex(m)
+            assert rel_err(out[:, :36], ref[:, :36]) < 1e-7, (hex(m), debug, rel_err(out[:, :36], ref[:, :36]))
+    for i in range(0, B, 16):
+        o = oracle_system(cfg2["dt"], cfg2["th"])
+        e = o.eval(cfg2["q0"], v[i], 0.0)
+        assert rel_err(ref[i, :24], e["tau"]) < TOL_REL and rel_err(ref[i, 24:36], e["f"]) < TOL_REL
+
+
 def test_cone_qp_kkt_at_scale(cfg2):
     """Optimality of the contact-force QP, independent of the oracle: for 1024 strongly perturbed states in each
     support phase the kernel's coefficients c must satisfy the KKT conditions of
