@@ -644,15 +644,24 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
     SUBSTAMP(2);
     const int f_lo = (NW == 2 && wid == 1) ? 14 : 1;               // first frame of the E, p loop
     const int f_n = (NW == 1) ? 27 : (wid ? 14 : 13);
-    for (int e = lane; e < f_n * 12; e += 64) {                    // frames 1..27: E = Rp' Ri, p = Rp' pi + (-Rp') pp
-        const int i = f_lo + e / 12, el = e % 12;
+    {   // frames 1..27: E = Rp' Ri, p = Rp' pi + (-Rp') pp.  Lane = (frame slot fr < 5, entry el < 12): everything derived from
+        // el is a per-lane constant, only the frame index moves from round to round (five frames per round)
+        const int fr = (lane < 60) ? lane / 12 : 0, el = lane % 12;
         const bool isE = el < 9;
         const int a = isE ? el / 3 : el - 9, col = isE ? el % 3 : 3;
-        const LV<R> Ti = L + A_T + 12 * i + col, Tp = L + A_T + 12 * f_parent(i);
-        const R t0 = Tp[a], t1 = Tp[4 + a], t2 = Tp[8 + a];
-        const R s1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
-        const R s2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
-        L[(isE ? A_XE + 9 * i + el : A_XP + 3 * i + (el - 9))] = isE ? s1 : s1 + s2;
+        const int sbase = isE ? A_XE + el : A_XP + (el - 9), sstr = isE ? 9 : 3;
+        constexpr int ROUNDS = (NW == 1) ? 6 : 3;
+#pragma unroll
+        for (int u = 0; u < ROUNDS; u++) {
+            const int fo = 5 * u + fr;
+            const bool on = (lane < 60) && (fo < f_n);
+            const int i = f_lo + (on ? fo : 0);
+            const LV<R> Ti = L + A_T + 12 * i + col, Tp = L + A_T + 12 * f_parent(i);
+            const R t0 = Tp[a], t1 = Tp[4 + a], t2 = Tp[8 + a];
+            const R s1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
+            const R s2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
+            if (on) L[sbase + sstr * i] = isE ? s1 : s1 + s2;
+        }
     }
     if (wid == 0 && lane < 12) {                                   // frame 0: E = R0, p = p0
         const LV<R> T0 = L + A_T;
@@ -662,14 +671,20 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
     WSYNC();
     SUBSTAMP(3);
     const int b_lo = (NW == 2 && wid == 1) ? 14 : 0, b_n = (NW == 1) ? 28 : 14;
-    for (int e = lane; e < b_n * 9; e += 64) {
-        const int i = b_lo + e / 9, a = (e % 9) / 3, b = e % 3;
-        const LV<R> E = L + A_XE + 9 * i, p = L + A_XP + 3 * i;
-        R val;                                               // B = (-E') [p]x
-        if (b == 0) val = (-E[3 + a]) * p[2] + E[6 + a] * p[1];
-        else if (b == 1) val = E[a] * p[2] + (-E[6 + a]) * p[0];
-        else val = (-E[a]) * p[1] + E[3 + a] * p[0];
-        L[A_XB + 9 * b_lo + e] = val;
+    {   // B = (-E') [p]x, entry (a, b) = sg1 E[i1] p[j1] + sg2 E[i2] p[j2]; lane = (frame slot < 7, entry < 9), seven frames per round
+        const int fr = (lane < 63) ? lane / 9 : 0, e9 = lane % 9, a = e9 / 3, bb = e9 % 3;
+        const int i1 = (bb == 0) ? 3 + a : a, j1 = (bb == 2) ? 1 : 2, i2 = (bb == 2) ? 3 + a : 6 + a, j2 = (bb == 0) ? 1 : 0;
+        const R sg1 = (bb == 1) ? (R)1 : (R)-1, sg2 = (bb == 1) ? (R)-1 : (R)1;
+        constexpr int ROUNDS = (NW == 1) ? 4 : 2;
+#pragma unroll
+        for (int u = 0; u < ROUNDS; u++) {
+            const int fo = 7 * u + fr;
+            const bool on = (lane < 63) && (fo < b_n);
+            const int i = b_lo + (on ? fo : 0);
+            const LV<R> E = L + A_XE + 9 * i, p = L + A_XP + 3 * i;
+            const R val = (sg1 * (R)E[i1]) * (R)p[j1] + (sg2 * (R)E[i2]) * (R)p[j2];
+            if (on) L[A_XB + 9 * i + e9] = val;
+        }
     }
     WSYNC();
     SUBSTAMP(4);
