@@ -557,11 +557,13 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
 {
     const int lane = LANE;
     // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos
+    // lane = (slot fr < 5, entry el < 12): five of the 28 local transforms per round, six rounds
+    const int lfr = (lane < 60) ? lane / 12 : 0, lel = lane % 12;
     R c0[6], c1[6], c2[6];
 #pragma unroll
     for (int u = 0; u < 6; u++) {
-        const int e = lane + 64 * u;
-        const LV<R> cf = lcoef + 3 * ((e < 336) ? e : 0);
+        const int sl = 5 * u + lfr;
+        const LV<R> cf = lcoef + 3 * (12 * ((sl < 28) ? sl : 0) + lel);
         c0[u] = cf[0]; c1[u] = cf[1]; c2[u] = cf[2];
     }
     if (lane < 28) {
@@ -580,12 +582,10 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
     {
 #pragma unroll
         for (int u = 0; u < 6; u++) {
-            const int e = lane + 64 * u;
-            if (e < 336) {
-                const int sl = e / 12;
-                const int ss = (sl < 25) ? sl : 24;                // slots 25..27 are constants (c1 = c2 = 0)
-                L[A_LC + e] = fma(c2[u], L[P_SC + 2 * ss], fma(c1[u], L[P_SC + 2 * ss + 1], c0[u]));
-            }
+            const int sl = 5 * u + lfr;
+            const int ss = (sl < 25) ? sl : 24;                    // slots 25..27 are constants (c1 = c2 = 0)
+            const R val = fma(c2[u], (R)L[P_SC + 2 * ss], fma(c1[u], (R)L[P_SC + 2 * ss + 1], c0[u]));
+            if (lane < 60 && sl < 28) L[A_LC + 12 * sl + lel] = val;
         }
     }
     if (lane < 12) {                                               // T0 = [R(rpy) p]
