@@ -989,25 +989,27 @@ __device__ __forceinline__ void phase_jacobian(LV<R> L)
     if (lane < 36) {                                               // Xn = X_sole : A = E', B
         L[A_XN + 36 * 0 + 18 * foot + el] = half ? L[A_XB + 9 * sole + 3 * r + c] : L[A_XE + 9 * sole + 3 * c + r];
     }
-    int cur = 0;
-    for (int s = 0; s < 6; s++) {
+    const bool jon = lane < 36;
+    const R mh = half ? (R)1 : (R)0;                               // the B half also takes A_n B_f
+    const int fsafe = jon ? foot : 0;
+#pragma unroll
+    for (int s = 0; s < 6; s++) {                                  // straight-line steps, guarded stores
         WSYNC();
-        const int f = sole - 1 - s;                                // frame 6..1 / 13..8
-        if (lane < 36) {
-            const LV<R> An = L + A_XN + 36 * cur + 18 * foot, Bn = An + 9;
-            const LV<R> E = L + A_XE + 9 * f, Bf = L + A_XB + 9 * f;
-            if (c == 2) L[A_JL + 72 * foot + 12 * (3 * half + r) + 6 + (5 - s)] = (half ? Bn : An)[3 * r + 2];   // Xn S
-            R val;                                            // A_f[k][c] = E[c][k]
-            if (!half) val = An[3 * r] * E[3 * c] + An[3 * r + 1] * E[3 * c + 1] + An[3 * r + 2] * E[3 * c + 2];
-            else val = Bn[3 * r] * E[3 * c] + Bn[3 * r + 1] * E[3 * c + 1] + Bn[3 * r + 2] * E[3 * c + 2]
-                     + An[3 * r] * Bf[c] + An[3 * r + 1] * Bf[3 + c] + An[3 * r + 2] * Bf[6 + c];
-            L[A_XN + 36 * (cur ^ 1) + 18 * foot + el] = val;
-        }
-        cur ^= 1;
+        const int cur = s & 1;
+        const int f = (fsafe ? 14 : 7) - 1 - s;                    // frame 6..1 / 13..8
+        const LV<R> An = L + A_XN + 36 * cur + 18 * fsafe, Bn = An + 9;
+        const LV<R> E = L + A_XE + 9 * f, Bf = L + A_XB + 9 * f;
+        const LV<R> P1 = half ? Bn : An;                           // picked by address
+        const R xs = P1[3 * r + 2];                                // Xn S (z column)
+        const R t1 = P1[3 * r] * E[3 * c] + P1[3 * r + 1] * E[3 * c + 1] + xs * E[3 * c + 2];   // A_f[k][c] = E[c][k]
+        const R t2 = An[3 * r] * Bf[c] + An[3 * r + 1] * Bf[3 + c] + An[3 * r + 2] * Bf[6 + c];
+        const R val = t1 + mh * t2;
+        if (jon && c == 2) L[A_JL + 72 * foot + 12 * (3 * half + r) + 6 + (5 - s)] = xs;
+        if (jon) L[A_XN + 36 * (cur ^ 1) + 18 * foot + el] = val;
     }
     WSYNC();
     if (lane < 36) {                                               // base block [A 0; B A]
-        const LV<R> An = L + A_XN + 36 * cur + 18 * foot, Bn = An + 9;
+        const LV<R> An = L + A_XN + 18 * foot, Bn = An + 9;     // after six steps the product sits in buffer 0
         if (!half) { L[A_JL + 72 * foot + 12 * r + c] = An[3 * r + c]; L[A_JL + 72 * foot + 12 * r + 3 + c] = 0.0; L[A_JL + 72 * foot + 12 * (3 + r) + 3 + c] = An[3 * r + c]; }
         else L[A_JL + 72 * foot + 12 * (3 + r) + c] = Bn[3 * r + c];
     }
