@@ -1890,7 +1890,6 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     *Fmask_io = F;
     *iters_out = it;
     if (lane == 0) L[P_KF] = (double)F;                            // published for the helper wave (next evaluation's warm start)
-    bsync<NW>();
     if (dbgp && LANE == 0) dbgp[4013] = (double)clock64();
     // ---- recover w = G c, lam = -Si (Jb' w - d), a = -(Y_g + Y_M lam)
     if (lane < 12) {
@@ -1917,11 +1916,14 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         L[P_A + lane] = -s;
     }
     WSYNC();
+    bsync<NW>();                                                   // the helper wave takes over from here: torques, then K^-1 and references of the next evaluation
     return flags;
 }
 
 // Controller::WBC tail (controller.cpp:134-153): tau, base acceleration back to the world frame.
-__device__ __forceinline__ void phase_outputs(double *L)
+// The torques are not needed by the integrator: on the two-wave schedule the helper wave computes them while wave 0
+// already updates the state and runs the next forward kinematics.
+__device__ __forceinline__ void phase_outputs_tau(double *L)
 {
     const int lane = LANE;
     if (lane < 24) {
@@ -1934,6 +1936,11 @@ __device__ __forceinline__ void phase_outputs(double *L)
         if (ft >= 0) for (int rr = 0; rr < 6; rr++) jw += L[P_JC + 72 * ft + 12 * rr + 6 + (a - 6 * ft)] * L[P_W12 + 6 * ft + rr];
         L[P_TAU + a] = s + L[P_C + 6 + a] - jw;
     }
+    WSYNC();
+}
+__device__ __forceinline__ void phase_outputs_qdd(double *L)
+{
+    const int lane = LANE;
     if (lane >= 32 && lane < 38) {                                 // X0 acc = a[0:6]: w = R0 a_ang ; v = R0 (a_lin - B0 w)
         const int k = lane - 32, r = k % 3;
         const double *E0 = L + P_X0, *B0 = L + P_X0 + 12, *a = L + P_A;
@@ -2013,7 +2020,8 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     STAMP(7);
     flags |= phase_qp<NW>(L, P, ph, wid, Fmask, iters_out, dbg);
     STAMP(8);
-    if (wid == 0) phase_outputs(L);
+    if constexpr (NW == 1) { phase_outputs_tau(L); phase_outputs_qdd(L); }
+    else { if (wid == 0) phase_outputs_qdd(L); else phase_outputs_tau(L); }
     STAMP(9);
     if (dbg) {
         const int lane = LANE;
@@ -2030,8 +2038,10 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         for (int e = lane; e < 32; e += 64) { dbg[3117 + e] = L[P_QV + e]; dbg[3149 + e] = L[P_CC + e]; }
     }
     // non-finite guard (reference aborts on NaN/Inf, controller.cpp:448-466)
+    // checked on the QP solution (accelerations, contact wrench): tau = M a + C - J'w is finite iff they are, and the
+    // torques may still be in flight on the helper wave
     double chk = 0.0;
-    if (LANE < 24) chk = L[P_TAU + LANE]; else if (LANE < 36) chk = L[P_W12 + LANE - 24];
+    if (LANE < 30) chk = L[P_A + LANE]; else if (LANE >= 32 && LANE < 44) chk = L[P_W12 + LANE - 32];
     const bool nf = !(fabs(chk) <= 1.0e300);
     if (__ballot(nf) != 0ull) flags |= LMH_FLAG_NONFINITE;
     return flags;
@@ -2115,6 +2125,7 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, doubl
     if constexpr (NW == 2) { if (wid == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }   // see lmh_rollout_kernel
     int k = 0, iters = 0;
     const int flags = controller_eval<NW, R>(L, P, inst, t, wid, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    bsync<NW>();                                                   // torques of the helper wave
     if (wid == 0) {
         store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
         if (LANE < 30) st[60 + LANE] = L[P_V + LANE];              // Robot::v_ <- dq (controller.cpp:59)
@@ -2200,15 +2211,15 @@ lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, 
                 else { ksum = ksum + xd; }
             }
         }
-        if (wid == 0) {
-            x = x + (dt / 6.0) * ksum;                              // rk4.hpp:17
-            if (log) {
-                double *lg = log + ((size_t)tick * P.n_instances + inst) * 36;
-                if (lane < 24) lg[lane] = L[P_TAU + lane]; else if (lane < 36) lg[lane] = L[P_W12 + lane - 24];
-            }
+        if (wid == 0) x = x + (dt / 6.0) * ksum;                    // rk4.hpp:17
+        if (log) {                                                  // each wave logs what it produced: wave 1 the torques, wave 0 the wrench
+            double *lg = log + ((size_t)tick * P.n_instances + inst) * 36;
+            if (wid != 0) { if (lane < 24) lg[lane] = L[P_TAU + lane]; }
+            else if (lane >= 24 && lane < 36) lg[lane] = L[P_W12 + lane - 24];
         }
         t += dt;                                                    // Clock::step, Clock.hpp:11
     }
+    bsync<2>();                                                    // the last torques (helper wave) are in LDS
     if (wid == 0) {
         WSYNC();
         store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
