@@ -25,7 +25,7 @@ ALG_BYTES_PER_TICK = 1248        # state in (60 f64) + state out (60)
 ALG_FLOP_PER_TICK = 8.0e5        # 2.0e5 flop per controller evaluation x 4
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP64_VALU_PEAK_TFLOPS = 78.6     # vendor fp64 vector peak
-PROFILE_TAG = "r01g"             # profiles/<tag>_rollout_summary.json: PMC passes of the kernel as committed
+PROFILE_TAG = "r01h"             # profiles/<tag>_rollout_summary.json: PMC passes of the kernel as committed
 
 
 def parse():
