@@ -2,63 +2,120 @@
 """Headline benchmark: control ticks/s/node of the batched NAO WBC+MPC closed loop.
 
 One "step" = one launch of the fused rollout kernel = `--ticks` RK4 control ticks (4 controller
-evaluations each) for every robot instance of this rank.  Workload at N=1 is BASELINE.json
-configs[1]: 1024 NAO instances, balance task, dt = 1 ms, LIPM-MPC horizon N = 16, WBC QP per
-evaluation; initial state = IK posture + per-instance velocity perturbation.
-Ranks shard instances (weak scaling: 1024 per GPU), no data-path collective; one RCCL gather of
-128-B per-instance summaries ends the run.
+evaluations each) for every robot instance of this rank.
+
+Workloads (BASELINE.json configs):
+  --config 3 (default at --gpus 1): configs[2], the largest single-GPU configuration: 4096 NAO instances, walking
+      (footRefTrajectory swing polynomials + piecewise ZMP, contact switching DS / SS-R / SS-L), per-instance step
+      length U(0.02, 0.05) m (seed 20260003 + i), dt = 1 ms, LIPM-MPC horizon N = 32, warm-started WBC QP, log on.
+  --config 4 (default at --gpus N > 1): configs[3], one GPU's share of it per rank: as config 3 plus per-link mass
+      x U(0.9, 1.1) and CoM +- 5 mm (seed 20260004 + i), start posture per instance from the IK KERNEL, per-instance
+      LIPM height; the end-of-run RCCL gather of 128-B summaries is inside the timed region.
+  --config 2: configs[1]: 1024 instances, balance task with velocity pushes, N = 16 (round 1's bench line).
+
+`--gpus N` with no RANK in the environment starts N child processes of this script (one per GPU, before anything
+touches the GPU) and relays rank 0's JSON line; under torchrun (RANK set) it is one rank.  Ranks shard instances
+(weak scaling), no data-path collective.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_TICK = 1248        # SURVEY 8d: state in (60 f64) + state out (60) + tau|f log (36)
-ALG_FLOP_PER_TICK = 8.0e5        # SURVEY 8d: 2.0e5 flop per controller evaluation x 4
+ALG_FLOP_PER_TICK = 8.0e5        # SURVEY 8d: nominal 2.0e5 flop per controller evaluation x 4
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E
-FP64_VALU_PEAK_TFLOPS = 78.6     # vendor fp64 vector peak
-PROFILE_TAG = "r01h"             # profiles/<tag>_rollout_summary.json: PMC passes of the kernel as committed
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak = 256 CU x 64 lanes x 2 flop x 2.4 GHz (SURVEY 8d)
+FP64_MFMA_PEAK_TFLOPS = 78.6     # v_mfma_f64_16x16x4_f64: fp64 matrix rate = fp64 vector rate on gfx950
+MFMA_MOP_FLOP = 512              # SQ_INSTS_VALU_MFMA_MOPS_F64 unit (one 16x16x4 f64 MFMA = 2048 flop = 4 MOPS)
+PROFILE_TAGS = {3: "r02_c3", 2: "r02_c2"}   # profiles/<tag>_rollout_summary.json: PMC passes of the committed kernel
+
+DEFAULTS = {2: dict(instances=1024, ticks=10, horizon=16, max_ticks=230),
+            3: dict(instances=4096, ticks=40, horizon=32, max_ticks=4000),
+            4: dict(instances=4096, ticks=40, horizon=32, max_ticks=4000)}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--instances", type=int, default=1024, help="robot instances per GPU")
-    ap.add_argument("--ticks", type=int, default=10, help="RK4 ticks per step (per launch)")
-    ap.add_argument("--horizon", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4),
+                    help="BASELINE config number (1-based); default 3 at --gpus 1, 4 (randomised models + IK kernel in set-up) otherwise")
+    ap.add_argument("--instances", type=int, default=None, help="robot instances per GPU")
+    ap.add_argument("--ticks", type=int, default=None, help="RK4 ticks per step (per launch)")
+    ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--cold", action="store_true", help="cold-start the QP active set every evaluation")
+    ap.add_argument("--no-log", action="store_true", help="do not write the per-tick tau|f log")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (all of its lines together)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
-    ap.add_argument("--reset-every", type=int, default=23,
-                    help="restart the rollouts from the initial states after this many steps (the reference's closed loop, "
-                         "which integrates the controller's own acceleration, leaves its valid range ~0.5 s after a 0.3 m/s push; "
-                         "DESIGN.md 'Long runs'); the default equals warmup + steps of the default run, i.e. no restart there")
-    ap.add_argument("--summary-out", default=None, help="write the gathered end-of-run summary (wire.write_summary format) to this path")
+    ap.add_argument("--reset-every", type=int, default=None,
+                    help="restart the rollouts from the initial states after this many steps; default: as many steps as fit the "
+                         "config's valid tick range (config 3/4: 4000 ticks = BASELINE's run length; config 2: 230 ticks, the pushed loop "
+                         "leaves its valid range ~0.5 s after a 0.3 m/s push, DESIGN.md 'Long runs')")
+    ap.add_argument("--summary-out", default=None, help="write the gathered end-of-run summary (lmh_write_summary format) to this path")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from rocprofv3 --pmc; default: the committed profiles/ summary when the workload matches it")
-    return ap.parse_args()
+    ap.add_argument("--precision", type=int, default=0, help="lmh_config.precision (0 fp64, 1 mixed, 2 fp32)")
+    args = ap.parse_args(argv)
+    if args.config is None:
+        args.config = 3 if args.gpus == 1 else 4
+    d = DEFAULTS[args.config]
+    for k in ("instances", "ticks", "horizon"):
+        if getattr(args, k) is None:
+            setattr(args, k, d[k])
+    if args.reset_every is None:
+        args.reset_every = max(1, d["max_ticks"] // args.ticks)
+    return args
 
 
-def ik_posture(device=0):
-    """IK start posture of apps/offline (feet (0,-/+0.05,0), CoM (-0.02,0,0.26)) and the LIPM height, computed by the
-    product's own IK kernel (Kinematics::compute on the GPU), as apps/offline/main.cpp:24-39 does at start-up."""
-    from linearmpchumanoid_amd.controller import ik_start_posture
-    return ik_start_posture(device)
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
+def launch_ranks(n):
+    """--gpus N without a launcher: start N fresh processes of this script (this parent has made no GPU / HIP call
+    and makes none), wait for them, exit non-zero if any rank failed.  Rank 0's JSON line goes to the inherited stdout."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            r = p.poll()
+            if r is None:
+                continue
+            pending.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in pending:                                  # a failed rank leaves the others in a collective: stop exactly those PIDs
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(rc if rc >= 0 else 1)
+
+
+# ------------------------------------------------------------------------------------------------ workload
 def perturbed_velocities(first, count, seed=20260001):
+    import numpy as np
     v = np.zeros((count, 30))
     for i in range(count):
         rng = np.random.default_rng(seed + first + i)
@@ -67,60 +124,217 @@ def perturbed_velocities(first, count, seed=20260001):
     return v
 
 
-def cpu_baseline(q0, zcom, args):
-    """Reference CPU path = the C oracle in reference-faithful mode, timed on this host's cores
-    on a bounded sample of the same workload (same states, same tick function)."""
-    from oracle import pyoracle
-    ncores = os.cpu_count() or 1
-    threads = max(1, min(ncores, 64))
-    th = args.horizon * args.dt
-    # calibrate: 1 instance x few ticks on one core
-    v = perturbed_velocities(0, threads * 2)
-    st = np.concatenate([np.broadcast_to(q0, (len(v), 30)), v], axis=1)
-    sec, _, _ = pyoracle.batch_rollout(st[:1], None, 0.0, args.dt, 5, 2.0, th, zcom, nthreads=1)
-    per_tick = sec / 5
-    ticks = max(5, int(args.cpu_seconds / max(per_tick, 1e-6) / 2))
-    ticks = min(ticks, 200)
-    sec1, _, _ = pyoracle.batch_rollout(st[:1], None, 0.0, args.dt, ticks, 2.0, th, zcom, nthreads=1)
-    one = ticks / sec1
-    tk = 100                                                  # same regime as the GPU run (first 0.1 s of the rollout)
-    n_inst = max(threads, int(args.cpu_seconds / 2 * one / tk) // threads * threads)
-    n_inst = min(n_inst, 4096)
-    v = perturbed_velocities(0, n_inst)
-    st = np.concatenate([np.broadcast_to(q0, (len(v), 30)), v], axis=1)
-    secN, _, _ = pyoracle.batch_rollout(st[:n_inst], None, 0.0, args.dt, tk, 2.0, th, zcom, nthreads=threads)
-    allc = n_inst * tk / secN
-    return {"value": allc, "unit": "control ticks/s", "cores": threads, "kind": "port",
-            "single_core_value": one,
-            "sample": f"C oracle (-O2), {n_inst} instances x {tk} ticks on {threads} threads; 1 instance x {ticks} ticks on 1 thread; same states/tick function as the GPU run, 1 WBC solve per evaluation"}
+def step_lengths(first, count, seed=20260003):
+    import numpy as np
+    return np.array([np.random.default_rng(seed + first + i).uniform(0.02, 0.05) for i in range(count)])
 
 
-def profiled_traffic(args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, profiles/<PROFILE_TAG>_rollout_summary.json, made by scripts/profile_rollout.sh +
-    scripts/summarise_profile.py); only valid for the workload it was collected on."""
-    if args.traffic is not None:
-        return args.traffic
-    if (args.instances, args.ticks, args.horizon) != (1024, 10, 16) or args.cold:
-        return None
+def randomised_links(first, count, seed=20260004):
+    """per-link mass x U(0.9,1.1), CoM + U(-5,5) mm per axis, on createNaoParameters() output."""
+    import numpy as np
+    from linearmpchumanoid_amd.controller import nominal_links
+    raw = np.tile(nominal_links(), (count, 1, 1))
+    for i in range(count):
+        rng = np.random.default_rng(seed + first + i)
+        raw[i, :, 0] *= rng.uniform(0.9, 1.1, 28)
+        raw[i, :, 1:4] += rng.uniform(-5e-3, 5e-3, (28, 3)) * (raw[i, :, 0:1] > 0)
+    return raw
+
+
+def build_workload(args, ctl, first, count, total_ticks):
+    """Uploads models / references for this rank's instances; returns (state0 tensor, dict of host-side inputs the
+    CPU baseline replays)."""
+    import numpy as np
+    import torch
+    from linearmpchumanoid_amd import trajectories
+    from linearmpchumanoid_amd.controller import ik_start_posture, initial_configuration
+    dev = ctl.device_index
+    host = {}
+    if args.config == 2:
+        q0, zcom = ik_start_posture(dev)
+        ctl.set_zcom(np.array([zcom]))
+        ctl.set_refs_stance(total_ticks * args.dt + 1.0, 2)
+        v = perturbed_velocities(first, count)
+        state = ctl.new_state(q0, v, t=0.0)
+        zx, zy = trajectories.stance_zmp(total_ticks * args.dt + 1.0, args.dt, 2)
+        host.update(q0=np.tile(q0, (count, 1)), v=v, zcom=np.array([zcom]), zmp_x=zx, zmp_y=zy, phase=None, segs=None, sos=None, xscale=None, raw=None)
+        return state, host
+    sim_time = total_ticks * args.dt + 0.5
+    n_steps = max(2, int((sim_time - 0.3) / 0.5))
+    plan = trajectories.walk_plan(sim_time, args.dt, num_steps=n_steps, time_per_step=0.5, ds_time=0.1, step_height=0.02, settle_time=0.3)
+    xs = step_lengths(first, count)
+    raw = None
+    if args.config == 4:
+        raw = randomised_links(first, count)
+        ctl.set_model(raw)
+        q = torch.as_tensor(np.tile(initial_configuration(), (count, 1))).to(ctl.device)
+        q, iters = ctl.ik(q)                                       # Kinematics::compute per instance on its own model
+        com = ctl.robot_com(q)
+        torch.cuda.synchronize(ctl.device)
+        q0s, zc = q.cpu().numpy(), com.cpu().numpy()[:, 2].copy()
+        if int(iters.max().item()) > 12:
+            raise RuntimeError("IK kernel did not converge on a randomised model")
+        ctl.set_zcom(zc)
+    else:
+        q0, zcom = ik_start_posture(dev)
+        q0s, zc = np.tile(q0, (count, 1)), np.array([zcom])
+        ctl.set_zcom(zc)
+    ctl.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+    ctl.set_segments(plan["segs"], plan["seg_of_sample"])
+    ctl.set_xscale(xs)
+    state = ctl.new_state(q0s, np.zeros(30), t=0.0)
+    host.update(q0=q0s, v=np.zeros((count, 30)), zcom=zc, zmp_x=plan["zmp_x"], zmp_y=plan["zmp_y"], phase=plan["phase"],
+                segs=plan["segs"], sos=plan["seg_of_sample"], xscale=xs, raw=raw)
+    return state, host
+
+
+WORKLOAD_TEXT = {
+    2: "{B} NAO instances/GPU, balance task (IK posture + velocity perturbation), dt={dt}, LIPM-MPC horizon N={N}, WBC QP per evaluation, RK4 closed loop",
+    3: "{B} NAO instances/GPU, walking (footRefTrajectory swing polynomials + piecewise ZMP, contact switching DS/SS-R/SS-L, per-instance step length U(0.02,0.05) m), dt={dt}, LIPM-MPC horizon N={N}, WBC QP per evaluation, RK4 closed loop",
+    4: "{B} NAO instances/GPU, walking with contact switching, domain-randomised link mass/CoM, per-instance IK start posture (IK kernel in set-up) and LIPM height, dt={dt}, LIPM-MPC horizon N={N}, WBC QP per evaluation, RK4 closed loop, end-of-run summary gather in the timed region",
+}
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cpu_info():
+    model = "unknown"
     try:
-        with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_rollout_summary.json")) as f:
-            d = json.load(f)["derived"]
-        return d["hbm_write_bytes_per_launch"] + d["hbm_fetch_bytes_per_launch_x2_gfx950_correction"]
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    usable = logical
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:                                                           # cgroup v2 CPU quota of the box's share
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()
+            if a != "max":
+                quota = float(a) / float(b)
+    except (OSError, ValueError):
+        pass
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return model, logical, usable, quota
+
+
+def _native_oracle():
+    """Second CPU line of BASELINE.md section 2: the same oracle sources built -O3 -march=native on THIS host."""
+    import ctypes as C
+    import tempfile
+    odir = os.path.join(ROOT, "oracle")
+    srcs = [os.path.join(odir, f) for f in ("orc_robot.c", "orc_dynamics.c", "orc_mpc.c", "orc_qp.c", "orc_controller.c", "orc_api.c")]
+    out = os.path.join(tempfile.mkdtemp(prefix="lmh_orc_native_"), "liblmh_oracle_native.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", out] + srcs + ["-lm", "-lpthread"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return C.CDLL(out)
+
+
+def cpu_baseline(args, host, total_ticks, gpu_out=None):
+    """Reference CPU path = the C oracle (restatement of the reference, dense cold-start active-set QP per evaluation), timed on
+    this host's cores on a bounded sample of the SAME workload: the first n robots of rank 0 over the same tick range the
+    GPU ran (warm-up + timed steps), static partition over threads.  Lines: one core; all usable cores (the reported value);
+    all cores with the reference's literal duplicate WBC call + per-call MPC Hessian rebuild (apps/offline/main.cpp:103-105,
+    mpcLinearPendulum.cpp:89-90); all cores with -O3 -march=native."""
+    import numpy as np
+    from oracle import pyoracle
+    model, logical, usable, quota = host_cpu_info()
+    th = args.horizon * args.dt
+    B = host["q0"].shape[0]
+
+    def run(idx, nticks, nthreads, wbc_calls=1, lib=None):
+        st = np.concatenate([host["q0"][idx], host["v"][idx]], axis=1)
+        zc = host["zcom"] if len(host["zcom"]) == 1 else host["zcom"][idx]
+        return pyoracle.batch_rollout_ex(st, 0.0, args.dt, nticks, th, host["zmp_x"], host["zmp_y"], host["phase"], host["segs"], host["sos"],
+                                         None if host["xscale"] is None else host["xscale"][idx], zc,
+                                         None if host["raw"] is None else host["raw"][idx], nthreads=nthreads, wbc_calls=wbc_calls, lib_override=lib)
+
+    sec, _, _ = run(np.arange(1), 20, 1)                         # calibrate: 1 robot x 20 ticks on one core
+    per_tick = sec / 20
+    budget = args.cpu_seconds / 4.0                                # four lines
+    nt_full = total_ticks
+    per_robot = per_tick * nt_full
+    if per_robot <= budget:                                        # whole tick range per robot, as many robots as the budget allows
+        r = max(1, int(budget / per_robot))
+        n_inst, nticks = min(B, usable * r), nt_full
+    else:                                                          # range too long for the budget: one robot per thread, truncated range
+        n_inst, nticks = min(B, usable), max(20, int(budget / per_tick))
+    idx = np.arange(n_inst)
+    n1 = max(20, min(nticks, int(budget / per_tick)))
+    sec1, _, _ = run(np.arange(1), n1, 1)
+    secN, _, outN = run(idx, nticks, usable)
+    allc = n_inst * nticks / secN
+    res = {"value": allc, "unit": "control ticks/s", "cores": usable, "kind": "port",
+           "single_core_value": n1 / sec1, "cpu_model": model, "logical_cpus": logical, "cgroup_cpu_quota": quota,
+           "compiler_flags": "-O2 (reference's own CMake: -O1 -g + ASan/UBSan)",
+           "seconds": secN,
+           "sample": f"C oracle, first {n_inst} robots of the same workload x ticks 0..{nticks} of the {nt_full} the GPU ran, {usable} threads (static partition), "
+                     f"1 WBC solve per evaluation, cold-start dense active-set QP; single core: 1 robot x {n1} ticks"}
+    if gpu_out is not None and nticks == nt_full:                  # same robots, same tick count: the k4-stage tau|f of the last tick must agree
+        ref = outN
+        err = float(np.max(np.abs(gpu_out[:n_inst, :36] - ref) / np.maximum(1e-9 * np.abs(ref).max(), np.abs(ref).max(axis=1, keepdims=True))))
+        res["parity_vs_gpu_last_tick_max_rel"] = err
+    try:
+        sec2, _, _ = run(idx, nticks, usable, wbc_calls=2)
+        res["literal_2wbc_value"] = n_inst * nticks / sec2
+        res["literal_2wbc_note"] = "duplicate WBC(t) per evaluation + MPC Hessian rebuilt per call, as apps/offline/main.cpp:103-105 / mpcLinearPendulum.cpp:89-90 do"
+    except Exception as e:
+        res["literal_2wbc_value"] = None
+        res["literal_2wbc_note"] = f"failed: {e}"
+    try:
+        nat = _native_oracle()
+        sec3, _, _ = run(idx, nticks, usable, lib=nat)
+        res["native_O3_value"] = n_inst * nticks / sec3
+    except Exception as e:
+        res["native_O3_value"] = None
+        res["native_O3_note"] = f"failed: {e}"
+    return res
+
+
+def profiled_pmc(args):
+    """PMC figures per launch from the committed rocprofv3 passes (profiles/<tag>_rollout_summary.json, made by
+    scripts/profile_rollout.sh + scripts/summarise_profile.py on this same default command); only valid for the workload they
+    were collected on.  Returns (hbm traffic bytes per launch or None, MFMA f64 MOPS per evaluation or None, tag)."""
+    tag = PROFILE_TAGS.get(args.config)
+    d = DEFAULTS[args.config]
+    if tag is None or (args.instances, args.ticks, args.horizon) != (d["instances"], d["ticks"], d["horizon"]) or args.cold or args.precision:
+        return None, None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", tag + "_rollout_summary.json")) as f:
+            dd = json.load(f)["derived"]
+        return (dd["hbm_write_bytes_per_launch"] + dd["hbm_fetch_bytes_per_launch_x2_gfx950_correction"], dd["mfma_f64_mops_per_eval"], tag)
     except Exception:
-        return None
+        return None, None, None
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and "RANK" not in os.environ:
+        if args.gpus > 1:
+            launch_ranks(args.gpus)                                # never returns
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(env_world or "1")
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}")
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from linearmpchumanoid_amd.controller import BatchedController, default_config
     from linearmpchumanoid_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
@@ -131,18 +345,16 @@ def main():
 
     B = args.instances
     first, count = sharding.shard_range(B * world, world, rank)
-    q0, zcom = ik_posture(local_rank)
     th = args.horizon * args.dt
-    cfg = default_config(dt=args.dt, time_horizon=th, z_com=zcom, warm_start=0 if args.cold else 1)
+    cfg = default_config(dt=args.dt, time_horizon=th, z_com=0.26, warm_start=0 if args.cold else 1, precision=args.precision)
     ctl = BatchedController(count, cfg, device=local_rank)
     reset_every = max(1, args.reset_every)
-    total_ticks = min(args.warmup + args.steps, reset_every) * args.ticks
-    ctl.set_refs_stance(total_ticks * args.dt + 1.0, 2)
-    v = perturbed_velocities(first, count)
-    state = ctl.new_state(q0, v, t=0.0)
+    n_launch = args.warmup + args.steps
+    total_ticks = min(n_launch, reset_every) * args.ticks
+    state, host = build_workload(args, ctl, first, count, total_ticks)
     state0 = state.clone()
     out, status = ctl.new_out(), ctl.new_status()
-    log = torch.zeros((args.ticks, count, 36), dtype=torch.float64, device=ctl.device)
+    log = None if args.no_log else torch.zeros((args.ticks, count, 36), dtype=torch.float64, device=ctl.device)
 
     def barrier():
         if world > 1:
@@ -150,11 +362,13 @@ def main():
         torch.cuda.synchronize()
 
     done = 0
+    flags_acc = torch.zeros((), dtype=torch.int32, device=ctl.device)
 
     def step():
         nonlocal done
         if done and done % reset_every == 0:
-            state.copy_(state0)                               # device-to-device, inside the timed region when it happens
+            state.copy_(state0)                                   # device-to-device, inside the timed region when it happens
+            status.zero_()
         ctl.rollout(state, args.ticks, out, status, log)
         done += 1
 
@@ -167,59 +381,81 @@ def main():
     for _ in range(args.steps):
         step()
     ev1.record()
+    # end-of-run summary: 16 f64 per instance, gathered over RCCL (the only collective) -- inside the timed region
+    summary = sharding.make_summary(state, out, status, ctl)
+    if world > 1 and args.backend != "nccl":
+        summary = summary.cpu()
+    gathered = sharding.gather_summaries(summary, world, rank)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps              # HIP events on the launch stream (torch's current stream = the stream lmh_rollout is given)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    # end-of-run summary: 16 f64 per instance, gathered over RCCL (the only collective)
-    summary = sharding.make_summary(state, out, status)
-    if world > 1 and args.backend != "nccl":
-        summary = summary.cpu()
-    gathered = sharding.gather_summaries(summary, world, rank)
     flags = int((status[:, 2] != 0).sum().item())
+    if world > 1:
+        ft = torch.tensor([flags], dtype=torch.int64, device=ctl.device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        flags = int(ft.item())
     if rank == 0 and args.summary_out and gathered is not None:
-        from linearmpchumanoid_amd import wire
-        wire.write_summary(args.summary_out, gathered.cpu().numpy(), dt=args.dt)
+        ctl.write_summary(args.summary_out, gathered.cpu().numpy(), dt=args.dt)
 
+    rc = 0
     if rank == 0:
         total_instances = B * world
         ticks_total = total_instances * args.ticks * args.steps
         value = ticks_total / elapsed
         launch_s = kernel_ms * 1e-3
-        alg_bytes = count * args.ticks * ALG_BYTES_PER_TICK
-        achieved = alg_bytes / launch_s / 1e9
+        units = count * args.ticks                                 # robot-ticks one launch processes
+        alg_bytes = units * (ALG_BYTES_PER_TICK if log is not None else 960)
+        alg_flop = units * ALG_FLOP_PER_TICK
+        traffic, mops, tag = profiled_pmc(args)
+        fp64_t = alg_flop / launch_s / 1e12
+        hbm_g = alg_bytes / launch_s / 1e9
+        mfma = None
+        if mops is not None:
+            mt = units * 4 * mops * MFMA_MOP_FLOP / launch_s / 1e12
+            mfma = {"achieved_tflops": mt, "peak_tflops": FP64_MFMA_PEAK_TFLOPS, "frac": mt / FP64_MFMA_PEAK_TFLOPS,
+                    "mfma_f64_mops_per_eval": mops, "source": f"SQ_INSTS_VALU_MFMA_MOPS_F64 of the committed profile profiles/{tag}_rollout_summary.json x {MFMA_MOP_FLOP} flop"}
         res = {
             "metric": "control ticks/s/node (batched NAO WBC+MPC @1kHz)",
             "value": value, "unit": "control ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{B} NAO instances/GPU, balance task (IK posture + velocity perturbation), dt={args.dt}, LIPM-MPC horizon N={args.horizon}, WBC QP per evaluation, RK4 closed loop",
+            "vs_baseline": None, "dtype": {0: "f64", 1: "f64 (QP) / f32 (model terms)", 2: "f32 (+1 fp64 refinement step in the QP)"}[args.precision], "data": "synthetic",
+            "config": {"workload": WORKLOAD_TEXT[args.config].format(B=B, dt=args.dt, N=args.horizon), "baseline_config": args.config,
                        "instances_per_gpu": B, "ticks_per_step": args.ticks, "evaluations_per_tick": 4,
-                       "qp_start": "cold" if args.cold else "warm", "parallelism": f"instances sharded x{world}",
-                       "rollout_restarts": (args.warmup + args.steps - 1) // reset_every},
+                       "tick_range": [args.warmup * args.ticks, min(n_launch, reset_every) * args.ticks] if n_launch <= reset_every else f"restarts every {reset_every * args.ticks} ticks",
+                       "qp_start": "cold" if args.cold else "warm", "log": log is not None, "parallelism": f"instances sharded x{world}",
+                       "rollout_restarts": (n_launch - 1) // reset_every, "summary_gather_in_timed_region": True},
             "evaluations_per_s": value * 4,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": profiled_traffic(args), "kernel": "lmh_rollout_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "fp64_valu": {"achieved_tflops": count * args.ticks * ALG_FLOP_PER_TICK / launch_s / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                          "frac": count * args.ticks * ALG_FLOP_PER_TICK / launch_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          "note": "the path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY 8d)"},
+            "roofline": {"bound": "fp64-valu", "achieved": fp64_t, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64_t / FP64_VALU_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": None if traffic is None else f"committed profile profiles/{tag}_rollout_summary.json (WRITE_SIZE + 2 x FETCH_SIZE per launch)",
+                         "kernel": "lmh_rollout_kernel", "kernel_ms": kernel_ms, "units_per_launch": units,
+                         "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "binding resource: fp64 vector issue + LDS latency (SURVEY 8d); nominal 8.0e5 flop per tick, not a counted figure",
+                         "hbm": {"bound": "hbm", "achieved": hbm_g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_g / HBM_PEAK_GBS},
+                         "mfma": mfma},
             "instances_flagged": flags,
             "summary_rows_gathered": int(gathered.shape[0]) if gathered is not None else 0,
         }
-        if not args.no_cpu_baseline and world == 1:              # the CPU baseline is timed at N = 1 only
+        if not args.no_cpu_baseline and world == 1:              # the CPU baseline is timed on rank 0 at N = 1 only
             try:
-                res["cpu_baseline"] = cpu_baseline(q0, zcom, args)
+                g_out = out.cpu().numpy() if n_launch <= reset_every else None
+                res["cpu_baseline"] = cpu_baseline(args, host, total_ticks, g_out)
+                if res["cpu_baseline"].get("value"):
+                    res["vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is reported, never required for the GPU number
-                res["cpu_baseline"] = {"value": None, "unit": "control ticks/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(res))
+                res["cpu_baseline"] = {"value": None, "unit": "control ticks/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(res), flush=True)
+        if flags:
+            print(f"bench.py: {flags} instances raised a status flag inside the benchmarked tick range", file=sys.stderr)
+            rc = 3
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -59,6 +59,9 @@ extern "C" {
 /* arithmetic of the model-term phases (BASELINE config 5 tolerance sweep; build-defined, the reference is fp64 only) */
 #define LMH_PRECISION_FP64 0
 #define LMH_PRECISION_MIXED 1
+#define LMH_PRECISION_FP32 2      /* model terms, references and QP in fp32 arithmetic (push-through cone solve only, one fp64
+                                     residual-refinement step per solve); k = int(t/dt) stays fp64 */
+#define LMH_SUMMARY_WIDTH 16      /* end-of-run summary record (doubles per instance), see lmh_make_summary */
 
 enum {
     LMH_OK = 0,
@@ -83,8 +86,10 @@ typedef struct lmh_config {
     int32_t warm_start;    /* 1: start the active set from the previous evaluation's (same minimiser) */
     int32_t max_qp_iters;
     int32_t precision;     /* LMH_PRECISION_FP64 (reference arithmetic) | LMH_PRECISION_MIXED: model terms (kinematics, C, M, J) in
-                              fp32 arithmetic, references + QP in fp64; k = int(t/dt) is computed in fp64 in every mode */
-    int32_t reserved;
+                              fp32 arithmetic, references + QP in fp64 | LMH_PRECISION_FP32; k = int(t/dt) is computed in fp64 in every mode */
+    int32_t bpp_rounds;    /* block-principal-pivoting rounds of the contact-force QP before the Lawson-Hanson pass takes over:
+                              0 = default (10); n > 0 = cap at n rounds; < 0 = skip block pivoting, solve by Lawson-Hanson from the
+                              empty set (diagnostic: exercises the finite fall-back) */
 } lmh_config;
 
 typedef struct lmh_handle lmh_handle;
@@ -173,6 +178,21 @@ int lmh_ik_host(lmh_handle *h, double *q, const double *com_target, const double
 /* overwrite the staged Robot::v_ (v_prev) used by the next lmh_eval_host call: HOST [B][30] */
 int lmh_set_prev_velocity_host(lmh_handle *h, const double *v);
 int lmh_synchronize(lmh_handle *h, void *stream);
+
+/* ---- end-of-run summary and on-disk records (the reference writes nothing but stdout,
+ * apps/offline/main.cpp:86, so these formats are the build's own).
+ * lmh_make_summary: DEVICE in (state/out/status as lmh_rollout leaves them), DEVICE out [B][LMH_SUMMARY_WIDTH]:
+ *   base pose(6) | t | max|tau| | f_z R + f_z L | f_z R | f_z L | k | qp iterations | flags | active-bound count |
+ *   checksum (sum of the 60 state doubles, in index order).  This record is what the one RCCL gather moves. */
+int lmh_make_summary(lmh_handle *h, const double *d_state, const double *d_out, const int32_t *d_status, double *d_summary, void *stream);
+/* Files: 64-byte little-endian header { char magic[8] "LMHSUM1\0" | "LMHLOG1\0"; uint32 version = 1; uint32 dtype = 1 (f64);
+ * uint64 n_instances; uint64 n_ticks (0 for a summary); uint32 width (16 | 36); uint32 0; double dt; double t0; uint64 0 }
+ * followed by the raw f64 payload: summary [n][16]; log [n_ticks][n][36] = lmh_rollout's d_log copied to the host.
+ * HOST pointers.  Readers return LMH_ERR_BAD_ARG on a bad magic / version / size; `capacity` is in doubles. */
+int lmh_write_summary(const char *path, const double *summary, uint64_t n_instances, double dt);
+int lmh_read_summary(const char *path, double *summary, uint64_t capacity, uint64_t *n_instances, double *dt);
+int lmh_write_log(const char *path, const double *log, uint64_t n_ticks, uint64_t n_instances, double dt, double t0);
+int lmh_read_log(const char *path, double *log, uint64_t capacity, uint64_t *n_ticks, uint64_t *n_instances, double *dt, double *t0);
 
 #ifdef __cplusplus
 }

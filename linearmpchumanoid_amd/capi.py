@@ -22,7 +22,8 @@ FLAG_ZMP_RANGE = 4
 FLAG_NOT_SPD = 8
 
 PHASE_DOUBLE, PHASE_RIGHT, PHASE_LEFT, PHASE_FLIGHT = 0, 1, 2, 3
-PRECISION_FP64, PRECISION_MIXED = 0, 1   # lmh_config.precision (include/lmh.h)
+PRECISION_FP64, PRECISION_MIXED, PRECISION_FP32 = 0, 1, 2   # lmh_config.precision (include/lmh.h)
+SUMMARY_WIDTH = 16
 
 # every symbol include/lmh.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -31,6 +32,7 @@ EXPORTS = [
     "lmh_set_refs", "lmh_set_refs_stance", "lmh_set_foot_coeffs", "lmh_set_zcom", "lmh_get_mpc_gain",
     "lmh_eval", "lmh_eval_debug", "lmh_rollout", "lmh_ik", "lmh_eval_host", "lmh_set_prev_velocity_host",
     "lmh_synchronize", "lmh_robot_com", "lmh_robot_com_host", "lmh_last_out_host", "lmh_ik_host", "lmh_set_segments", "lmh_set_xscale",
+    "lmh_make_summary", "lmh_write_summary", "lmh_read_summary", "lmh_write_log", "lmh_read_log",
 ]
 
 
@@ -40,7 +42,7 @@ class LmhConfig(C.Structure):
         "dt", "time_horizon", "z_com", "gravity", "alpha", "beta", "mu",
         "kp_joints", "kd_joints", "kp_mom", "kd_mom", "kp_feet", "kd_feet",
         "w_com_lin", "w_com_ang", "w_base_pos", "w_base_ang", "w_joints", "w_force", "w_foot",
-        "eps_coeff")] + [("warm_start", C.c_int32), ("max_qp_iters", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32)]
+        "eps_coeff")] + [("warm_start", C.c_int32), ("max_qp_iters", C.c_int32), ("precision", C.c_int32), ("bpp_rounds", C.c_int32)]
 
 
 _lib = None
@@ -88,6 +90,12 @@ def lib():
     L.lmh_ik_host.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.lmh_set_segments.argtypes = [vp, vp, ip, vp, ip]
     L.lmh_set_xscale.argtypes = [vp, vp, ip]
+    u64, u64p, dpp = C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+    L.lmh_make_summary.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.lmh_write_summary.argtypes = [C.c_char_p, vp, u64, dp]
+    L.lmh_read_summary.argtypes = [C.c_char_p, vp, u64, u64p, dpp]
+    L.lmh_write_log.argtypes = [C.c_char_p, vp, u64, u64, dp, dp]
+    L.lmh_read_log.argtypes = [C.c_char_p, vp, u64, u64p, u64p, dpp, dpp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("lmh_last_error", "lmh_config_default", "lmh_nominal_links"):

@@ -49,8 +49,7 @@ def ik_start_posture(device=0, com_target=(-0.02, 0.0, 0.26)):
     ctl = BatchedController(1, default_config(), device=device)
     q = torch.as_tensor(initial_configuration()[None, :]).to(ctl.device)
     q, iters = ctl.ik(q, com_target=com_target)
-    com = torch.zeros((1, 3), dtype=torch.float64, device=ctl.device)
-    check(capi.lib().lmh_robot_com(ctl._h, _dev_ptr(q), _dev_ptr(com), ctl._stream()))
+    com = ctl.robot_com(q)
     torch.cuda.synchronize(ctl.device)
     out = q.cpu().numpy()[0].copy(), float(com.cpu().numpy()[0, 2])
     ctl.close()
@@ -202,6 +201,50 @@ class BatchedController:
         r6 = np.ascontiguousarray(rf, dtype=np.float64); l6 = np.ascontiguousarray(lf, dtype=np.float64)
         check(capi.lib().lmh_ik(self._h, _dev_ptr(q), _np_ptr(ct), _np_ptr(r6), _np_ptr(l6), _dev_ptr(iters), self._stream()))
         return q, iters
+
+    def robot_com(self, q):
+        """Robot::updateState + getCoM (Robot.cpp:264-269,225-238) for q [B,30] (device tensor) -> [B,3]."""
+        com = torch.zeros((self.B, 3), dtype=torch.float64, device=self.device)
+        check(capi.lib().lmh_robot_com(self._h, _dev_ptr(q), _dev_ptr(com), self._stream()))
+        return com
+
+    def make_summary(self, state, out, status):
+        """End-of-run summary [B,16] (include/lmh.h lmh_make_summary): the record the RCCL gather moves."""
+        s = torch.empty((self.B, capi.SUMMARY_WIDTH), dtype=torch.float64, device=self.device)
+        check(capi.lib().lmh_make_summary(self._h, _dev_ptr(state), _dev_ptr(out), _dev_ptr(status), _dev_ptr(s), self._stream()))
+        return s
+
+    @staticmethod
+    def write_summary(path, summary, dt=0.0):
+        """lmh_write_summary: [n,16] host array -> 64-byte header + raw f64 file."""
+        a = np.ascontiguousarray(summary, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != capi.SUMMARY_WIDTH:
+            raise ValueError("summary must be [n,16]")
+        check(capi.lib().lmh_write_summary(str(path).encode(), _np_ptr(a), a.shape[0], float(dt)))
+
+    @staticmethod
+    def read_summary(path):
+        n, dt = C.c_uint64(0), C.c_double(0.0)
+        check(capi.lib().lmh_read_summary(str(path).encode(), None, 0, C.byref(n), C.byref(dt)))      # header only
+        a = np.zeros((n.value, capi.SUMMARY_WIDTH), dtype=np.float64)
+        check(capi.lib().lmh_read_summary(str(path).encode(), _np_ptr(a), a.size, C.byref(n), C.byref(dt)))
+        return a, dt.value
+
+    @staticmethod
+    def write_log(path, log, dt, t0=0.0):
+        """lmh_write_log: [n_ticks,B,36] host array (lmh_rollout's d_log copied back)."""
+        a = np.ascontiguousarray(log, dtype=np.float64)
+        if a.ndim != 3 or a.shape[2] != 36:
+            raise ValueError("log must be [ticks,B,36]")
+        check(capi.lib().lmh_write_log(str(path).encode(), _np_ptr(a), a.shape[0], a.shape[1], float(dt), float(t0)))
+
+    @staticmethod
+    def read_log(path):
+        nt, n, dt, t0 = C.c_uint64(0), C.c_uint64(0), C.c_double(0.0), C.c_double(0.0)
+        check(capi.lib().lmh_read_log(str(path).encode(), None, 0, C.byref(nt), C.byref(n), C.byref(dt), C.byref(t0)))
+        a = np.zeros((nt.value, n.value, 36), dtype=np.float64)
+        check(capi.lib().lmh_read_log(str(path).encode(), _np_ptr(a), a.size, C.byref(nt), C.byref(n), C.byref(dt), C.byref(t0)))
+        return a, dt.value, t0.value
 
     @staticmethod
     def split_out(out):

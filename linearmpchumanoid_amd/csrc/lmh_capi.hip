@@ -17,7 +17,8 @@ extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *ou
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s);
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s);
-extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const double *target, int32_t *iters, hipStream_t s);
+extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const LmhIkTarget *target, int32_t *iters, hipStream_t s);
+extern "C" void lmh_launch_summary(int n, const double *state, const double *out, const int32_t *status, double *summary, hipStream_t s);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -32,7 +33,7 @@ struct lmh_handle {
     int n_seg = 0;
     uint8_t *d_phase = nullptr;
     // staging for the host-buffer convenience calls
-    double *d_state = nullptr, *d_out = nullptr, *d_tgt = nullptr;
+    double *d_state = nullptr, *d_out = nullptr;
     int32_t *d_status = nullptr;
     std::vector<double> h_state, h_out, h_gain;
     std::vector<int32_t> h_status;
@@ -60,7 +61,7 @@ extern "C" void lmh_config_default(lmh_config *c)
     c->w_com_lin = 4000; c->w_com_ang = 0; c->w_base_pos = 10; c->w_base_ang = 10;   // :118-121
     c->w_joints = 1; c->w_force = 1; c->w_foot = 100000;            // :122-124
     c->eps_coeff = 1e-8;                                            // controller.cpp:117
-    c->warm_start = 1; c->max_qp_iters = 64; c->precision = LMH_PRECISION_FP64;
+    c->warm_start = 1; c->max_qp_iters = 64; c->precision = LMH_PRECISION_FP64; c->bpp_rounds = 0;
 }
 
 extern "C" void lmh_nominal_links(double *raw) { std::memcpy(raw, kLmhNaoLinks, sizeof(kLmhNaoLinks)); }
@@ -219,6 +220,7 @@ static void fill_params(lmh_handle *h)
     P.mpc_stride_inst = (h->n_gain > 1) ? P.mpc_stride : 0;
     P.n_samples = h->n_samples; P.horizon = h->N; P.n_instances = h->B;
     P.warm_start = c.warm_start; P.max_qp_iters = c.max_qp_iters; P.precision = c.precision;
+    P.bpp_max = (c.bpp_rounds == 0) ? 10 : c.bpp_rounds;            // < 0: Lawson-Hanson from the empty set (diagnostic)
     P.dt = c.dt;
     P.kp_joints = c.kp_joints; P.kd_joints = c.kd_joints; P.kp_mom = c.kp_mom; P.kd_mom = c.kd_mom;
     P.kp_feet = c.kp_feet; P.kd_feet = c.kd_feet;
@@ -242,18 +244,28 @@ static int upload_gain(lmh_handle *h, const double *zcom, int n)
     return LMH_OK;
 }
 
-extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lmh_handle **out)
+// every literal the kernels divide by or take a Cholesky pivot from must be positive (a zero weight is 1/0 in the
+// Woodbury set-up; the reference has no such check because its literals are compile-time constants)
+static const char *validate_config(const lmh_config *c)
 {
-    if (!cfg || !out || n_instances < 1) return fail(LMH_ERR_BAD_ARG, "lmh_create: bad argument");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LMH_ERR_NO_DEVICE, "no HIP device: the controller has no CPU path");
-    if (device < 0 || device >= ndev) return fail(LMH_ERR_BAD_ARG, "lmh_create: device index out of range");
-    HIPCHK(hipSetDevice(device));
-    lmh_handle *h = new lmh_handle();
-    h->cfg = *cfg; h->B = n_instances; h->device = device;
-    h->N = (int)(cfg->time_horizon / cfg->dt);                      // mpcLinearPendulum.cpp:43
-    if (h->N < 1 || h->N > LMH_MAX_HORIZON) { delete h; return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/dt must be in [1, 64]"); }
-    if (cfg->precision != LMH_PRECISION_FP64 && cfg->precision != LMH_PRECISION_MIXED) { delete h; return fail(LMH_ERR_BAD_ARG, "precision must be LMH_PRECISION_FP64 or LMH_PRECISION_MIXED"); }
+    if (!(c->dt > 0.0) || !(c->time_horizon > 0.0)) return "dt and time_horizon must be positive";
+    if (!(c->z_com > 0.0) || !(c->gravity > 0.0)) return "z_com and gravity must be positive";
+    if (!(c->alpha > 0.0) || !(c->beta > 0.0)) return "alpha and beta must be positive";
+    if (!(c->mu > 0.0)) return "mu must be positive";
+    if (!(c->eps_coeff > 0.0)) return "eps_coeff must be positive";
+    if (!(c->w_com_lin > 0.0) || !(c->w_base_pos > 0.0) || !(c->w_base_ang > 0.0) || !(c->w_joints > 0.0) || !(c->w_force > 0.0) || !(c->w_foot > 0.0))
+        return "weights w_com_lin, w_base_pos, w_base_ang, w_joints, w_force, w_foot must be positive";
+    if (!(c->w_com_ang >= 0.0)) return "w_com_ang must be >= 0";
+    const double g[6] = {c->kp_joints, c->kd_joints, c->kp_mom, c->kd_mom, c->kp_feet, c->kd_feet};
+    for (double v : g) if (!std::isfinite(v)) return "PD gains must be finite";
+    if (c->max_qp_iters < 1) return "max_qp_iters must be >= 1";
+    if (c->precision != LMH_PRECISION_FP64 && c->precision != LMH_PRECISION_MIXED && c->precision != LMH_PRECISION_FP32)
+        return "precision must be LMH_PRECISION_FP64, LMH_PRECISION_MIXED or LMH_PRECISION_FP32";
+    return nullptr;
+}
+
+static int create_body(lmh_handle *h, const lmh_config *cfg, int n_instances)
+{
     std::memset(&h->P, 0, sizeof(h->P));
     double g[16 * 6 + 36 + 96 + 3 * 336];
     build_gcol(cfg->mu, g);
@@ -263,13 +275,11 @@ extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lm
     HIPCHK(hipMalloc(&h->d_state, sizeof(double) * LMH_STATE_STRIDE * (size_t)n_instances));
     HIPCHK(hipMalloc(&h->d_out, sizeof(double) * LMH_OUT_STRIDE * (size_t)n_instances));
     HIPCHK(hipMalloc(&h->d_status, sizeof(int32_t) * LMH_STATUS_STRIDE * (size_t)n_instances));
-    HIPCHK(hipMalloc(&h->d_tgt, sizeof(double) * 16));
     HIPCHK(hipMemset(h->d_state, 0, sizeof(double) * LMH_STATE_STRIDE * (size_t)n_instances));
     HIPCHK(hipMemset(h->d_status, 0, sizeof(int32_t) * LMH_STATUS_STRIDE * (size_t)n_instances));
     h->h_state.assign((size_t)LMH_STATE_STRIDE * n_instances, 0.0);
     h->h_out.assign((size_t)LMH_OUT_STRIDE * n_instances, 0.0);
     h->h_status.assign((size_t)LMH_STATUS_STRIDE * n_instances, 0);
-    *out = h;
     int rc = lmh_set_model(h, nullptr, 1);
     if (rc == LMH_OK) rc = upload_gain(h, &cfg->z_com, 1);
     if (rc == LMH_OK) rc = lmh_set_refs_stance(h, 5.0, 2);
@@ -279,7 +289,25 @@ extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lm
         r[8] = -0.05; l[8] = 0.05;
         rc = lmh_set_foot_coeffs(h, r, n, l, n);
     }
-    if (rc != LMH_OK) { std::string keep = g_err; lmh_destroy(h); *out = nullptr; g_err = keep; return rc; }
+    return rc;
+}
+
+extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lmh_handle **out)
+{
+    if (!cfg || !out || n_instances < 1) return fail(LMH_ERR_BAD_ARG, "lmh_create: bad argument");
+    *out = nullptr;
+    if (const char *why = validate_config(cfg)) return fail(LMH_ERR_BAD_ARG, std::string("lmh_create: ") + why);
+    const int N = (int)(cfg->time_horizon / cfg->dt);               // mpcLinearPendulum.cpp:43
+    if (N < 1 || N > LMH_MAX_HORIZON) return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/dt must be in [1, 64]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LMH_ERR_NO_DEVICE, "no HIP device: the controller has no CPU path");
+    if (device < 0 || device >= ndev) return fail(LMH_ERR_BAD_ARG, "lmh_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    lmh_handle *h = new lmh_handle();
+    h->cfg = *cfg; h->B = n_instances; h->device = device; h->N = N;
+    const int rc = create_body(h, cfg, n_instances);                // every failure path releases what was allocated so far
+    if (rc != LMH_OK) { std::string keep = g_err; lmh_destroy(h); g_err = keep; return rc; }
+    *out = h;
     return LMH_OK;
 }
 
@@ -287,7 +315,7 @@ extern "C" int lmh_destroy(lmh_handle *h)
 {
     if (!h) return LMH_OK;
     (void)hipSetDevice(h->device);
-    void *bufs[] = {h->d_model, h->d_mpc, h->d_zx, h->d_zy, h->d_gcol, h->d_raw, h->d_phase, h->d_state, h->d_out, h->d_status, h->d_tgt,
+    void *bufs[] = {h->d_model, h->d_mpc, h->d_zx, h->d_zy, h->d_gcol, h->d_raw, h->d_phase, h->d_state, h->d_out, h->d_status,
                     h->d_segs, h->d_xscale, h->d_sos};
     for (void *b : bufs) if (b) (void)hipFree(b);
     delete h;
@@ -461,12 +489,11 @@ extern "C" int lmh_ik(lmh_handle *h, double *d_q, const double *com_target, cons
     int rc = ready(h); if (rc) return rc;
     if (!d_q || !com_target || !rf6 || !lf6) return fail(LMH_ERR_BAD_ARG, "bad argument");
     HIPCHK(hipSetDevice(h->device));
-    double tgt[16] = {0};
-    for (int k = 0; k < 6; k++) { tgt[k] = rf6[k]; tgt[6 + k] = lf6[k]; }
-    for (int k = 0; k < 3; k++) tgt[12 + k] = com_target[k];
-    HIPCHK(hipMemcpyAsync(h->d_tgt, tgt, sizeof(tgt), hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));              // tgt lives on this stack frame
-    lmh_launch_ik(&h->P, d_q, h->d_tgt, d_iters, (hipStream_t)stream);
+    LmhIkTarget tgt;                                                 // travels by value in the kernel arguments: no shared staging buffer, no sync
+    for (int k = 0; k < 6; k++) { tgt.v[k] = rf6[k]; tgt.v[6 + k] = lf6[k]; }
+    for (int k = 0; k < 3; k++) tgt.v[12 + k] = com_target[k];
+    tgt.v[15] = 0.0;
+    lmh_launch_ik(&h->P, d_q, &tgt, d_iters, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return LMH_OK;
 }
@@ -559,5 +586,96 @@ extern "C" int lmh_synchronize(lmh_handle *h, void *stream)
     if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return LMH_OK;
+}
+
+// ---------------------------------------------------------------------------- end-of-run summary + on-disk records
+extern "C" int lmh_make_summary(lmh_handle *h, const double *d_state, const double *d_out, const int32_t *d_status, double *d_summary, void *stream)
+{
+    if (!h || !d_state || !d_out || !d_status || !d_summary) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    lmh_launch_summary(h->B, d_state, d_out, d_status, d_summary, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return LMH_OK;
+}
+
+namespace {
+#pragma pack(push, 1)
+struct RecHeader {                                                   // 64 bytes, little-endian (include/lmh.h)
+    char magic[8]; uint32_t version, dtype; uint64_t n_instances, n_ticks; uint32_t width, pad0; double dt, t0; uint64_t pad1;
+};
+#pragma pack(pop)
+static_assert(sizeof(RecHeader) == 64, "record header is 64 bytes");
+const char kMagicSum[8] = {'L', 'M', 'H', 'S', 'U', 'M', '1', 0}, kMagicLog[8] = {'L', 'M', 'H', 'L', 'O', 'G', '1', 0};
+
+int write_rec(const char *path, const char *magic, const double *data, uint64_t n_inst, uint64_t n_ticks, uint32_t width, double dt, double t0)
+{
+    if (!path || !data) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(LMH_ERR_BAD_ARG, std::string("cannot open ") + path);
+    RecHeader hd;
+    std::memset(&hd, 0, sizeof(hd));
+    std::memcpy(hd.magic, magic, 8);
+    hd.version = 1; hd.dtype = 1; hd.n_instances = n_inst; hd.n_ticks = n_ticks; hd.width = width; hd.dt = dt; hd.t0 = t0;
+    const size_t count = (size_t)n_inst * width * (size_t)(n_ticks ? n_ticks : 1);
+    const bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1 && (count == 0 || std::fwrite(data, sizeof(double), count, f) == count);
+    if (std::fclose(f) != 0 || !ok) return fail(LMH_ERR_BAD_ARG, std::string("short write to ") + path);
+    return LMH_OK;
+}
+
+int read_rec(const char *path, const char *magic, uint32_t width, double *data, uint64_t capacity, RecHeader *hd)
+{
+    if (!path || !hd) return fail(LMH_ERR_BAD_ARG, "bad argument");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(LMH_ERR_BAD_ARG, std::string("cannot open ") + path);
+    int rc = LMH_OK;
+    if (std::fread(hd, sizeof(*hd), 1, f) != 1) rc = fail(LMH_ERR_BAD_ARG, "truncated header");
+    else if (std::memcmp(hd->magic, magic, 8) != 0) rc = fail(LMH_ERR_BAD_ARG, "bad magic");
+    else if (hd->version != 1 || hd->dtype != 1 || hd->width != width) rc = fail(LMH_ERR_BAD_ARG, "unsupported version / dtype / width");
+    else {
+        const bool is_log = std::memcmp(magic, kMagicLog, 8) == 0;
+        const uint64_t count = hd->n_instances * width * (is_log ? hd->n_ticks : 1);
+        long pos = std::ftell(f);
+        std::fseek(f, 0, SEEK_END);
+        const long end = std::ftell(f);
+        std::fseek(f, pos, SEEK_SET);
+        if ((uint64_t)(end - pos) != count * sizeof(double)) rc = fail(LMH_ERR_BAD_ARG, "payload size does not match the header");
+        else if (data) {
+            if (capacity < count) rc = fail(LMH_ERR_BAD_ARG, "buffer too small");
+            else if (count && std::fread(data, sizeof(double), (size_t)count, f) != count) rc = fail(LMH_ERR_BAD_ARG, "short read");
+        }
+    }
+    std::fclose(f);
+    return rc;
+}
+}  // namespace
+
+extern "C" int lmh_write_summary(const char *path, const double *summary, uint64_t n_instances, double dt)
+{
+    return write_rec(path, kMagicSum, summary, n_instances, 0, LMH_SUMMARY_WIDTH, dt, 0.0);
+}
+extern "C" int lmh_read_summary(const char *path, double *summary, uint64_t capacity, uint64_t *n_instances, double *dt)
+{
+    RecHeader hd;
+    const int rc = read_rec(path, kMagicSum, LMH_SUMMARY_WIDTH, summary, capacity, &hd);
+    if (rc != LMH_OK) return rc;
+    if (n_instances) *n_instances = hd.n_instances;
+    if (dt) *dt = hd.dt;
+    return LMH_OK;
+}
+extern "C" int lmh_write_log(const char *path, const double *log, uint64_t n_ticks, uint64_t n_instances, double dt, double t0)
+{
+    if (n_ticks == 0) return fail(LMH_ERR_BAD_ARG, "a log holds at least one tick");
+    return write_rec(path, kMagicLog, log, n_instances, n_ticks, 36, dt, t0);
+}
+extern "C" int lmh_read_log(const char *path, double *log, uint64_t capacity, uint64_t *n_ticks, uint64_t *n_instances, double *dt, double *t0)
+{
+    RecHeader hd;
+    const int rc = read_rec(path, kMagicLog, 36, log, capacity, &hd);
+    if (rc != LMH_OK) return rc;
+    if (n_ticks) *n_ticks = hd.n_ticks;
+    if (n_instances) *n_instances = hd.n_instances;
+    if (dt) *dt = hd.dt;
+    if (t0) *t0 = hd.t0;
     return LMH_OK;
 }

@@ -7,6 +7,8 @@
 #define LMH_SEG_STRIDE 52
 #define LMH_ROLLOUT_THREADS 128   // fused rollout: two waves per robot (lmh_kernels.hip, bsync)
 
+struct LmhIkTarget { double v[16]; };   // rF(6) | lF(6) | com(3) | pad: passed by value in the IK kernel's arguments
+
 struct LmhDevParams {
     // ---- device buffers
     const double *model;        // [n_models][LMH_MODEL_STRIDE]
@@ -27,7 +29,8 @@ struct LmhDevParams {
     int32_t n_instances;
     int32_t warm_start;
     int32_t max_qp_iters;
-    int32_t precision;          // 0: fp64 throughout; 1: mixed (fp32 model terms, fp64 references + QP)
+    int32_t precision;          // 0: fp64 throughout; 1: mixed (fp32 model terms, fp64 references + QP); 2: fp32
+    int32_t bpp_max;            // block-pivoting rounds before the Lawson-Hanson pass (< 0: Lawson-Hanson only)
     // ---- scalars (reference literals, see include/lmh.h lmh_config)
     double dt;
     double kp_joints, kd_joints, kp_mom, kd_mom, kp_feet, kd_feet;

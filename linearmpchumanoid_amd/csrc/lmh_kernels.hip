@@ -1565,7 +1565,7 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
 // the active set did not change, typically <= 8 from a cold start).  If that has not settled after
 // BPP_MAX rounds, a Lawson-Hanson active-set pass from the empty set finishes (monotone, finite).
 // One loop, one call site of the (large, fully unrolled) free-set solve.
-#define BPP_MAX 10
+// P.bpp_max (lmh_config.bpp_rounds): 10 by default; < 0 skips block pivoting altogether (diagnostic: Lawson-Hanson from the empty set)
 __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters, double *dbgp = nullptr)
 {
     const int lane = LANE;
@@ -1578,11 +1578,13 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
                                                                    // out whose multiplier is slightly negative (1e-6 relative error in tau after a contact switch)
     const bool mine = (lane < 32) && !((forced >> lane) & 1u);
     int ninf = 33, budget = 3;
-    bool lh = false;                                               // false: block pivoting, true: Lawson-Hanson
+    const int bpp_max = P.bpp_max;
+    bool lh = bpp_max < 0;                                         // false: block pivoting, true: Lawson-Hanson
+    if (lh) F = 0u;
     bool have_p = false;                                           // cone Hessian formed (general solve only)
     if (dbgp) { build_cone_matrix(L, P); have_p = true; }          // the debug record dumps it
     double cj = 0.0, lj = 0.0;
-    if (forced == 0u && F == 0xFFFFFFFFu) {
+    if (!lh && forced == 0u && F == 0xFFFFFFFFu) {
         // every coefficient free (the usual balance case): then w = G c solves the 12 x 12 SPD system
         // (W + eps (G G')^-1) w = h and c = G'(G G')^-1 w  (push-through identity; G G' is constant,
         // block diagonal and well conditioned) -- 12 pivots instead of 32.
@@ -1648,7 +1650,7 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
             if (dbgp && lane == 0 && it <= 12) { dbgp[3960 + it] = (double)F; dbgp[3975 + it] = (double)bad; }   // round trace (diagnostics)
             cj = zj;
             if (bad == 0u) break;
-            if (it >= BPP_MAX) { lh = true; F = 0u; cj = 0.0; continue; }    // next solve: F empty, lam = -qv
+            if (it >= bpp_max) { lh = true; F = 0u; cj = 0.0; continue; }    // next solve: F empty, lam = -qv
             const int nb = __popc(bad);
             if (nb < ninf) { ninf = nb; budget = 3; F ^= bad; }
             else if (budget > 0) { budget--; F ^= bad; }
@@ -2312,7 +2314,7 @@ __device__ void inv3_dev(const double *A, double *Ai)
     Ai[6] = (A[3] * A[7] - A[4] * A[6]) / det; Ai[7] = (A[1] * A[6] - A[0] * A[7]) / det; Ai[8] = (A[0] * A[4] - A[1] * A[3]) / det;
 }
 
-__global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio, const double *target, int32_t *iters_out)
+__global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio, LmhIkTarget tgt, int32_t *iters_out)
 {
     __shared__ double L[IK_LDS];
     const int inst = blockIdx.x;
@@ -2324,10 +2326,13 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
     WSYNC();
     // desiredOperationalState (:11-25): feet pose, CURRENT arm/head joints, zero base attitude, CoM target
     double des = 0.0;
-    if (lane < 12) des = target[lane];
+    if (lane < 16) L[IK_E + lane] = tgt.v[lane];                  // kernel-argument record -> LDS (a per-lane index into it would be a scratch copy)
+    WSYNC();
+    if (lane < 12) des = L[IK_E + lane];
     else if (lane < 24) des = L[P_Q + 18 + (lane - 12)];
     else if (lane < 27) des = 0.0;
-    else if (lane < 30) des = target[12 + (lane - 27)];
+    else if (lane < 30) des = L[IK_E + 12 + (lane - 27)];
+    WSYNC();
     const double mass = L[P_MODEL + 392];
     int iter = 0;
     for (;;) {
@@ -2468,9 +2473,32 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio,
     if (lane == 0 && iters_out) iters_out[inst] = iter;
 }
 
-extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const double *target, int32_t *iters, hipStream_t s)
+extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const LmhIkTarget *target, int32_t *iters, hipStream_t s)
 {
-    hipLaunchKernelGGL(lmh_ik_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, target, iters);
+    hipLaunchKernelGGL(lmh_ik_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, *target, iters);
+}
+
+// End-of-run summary: 16 doubles per instance, the record the one RCCL gather moves.  One lane per robot; HBM-bound
+// (reads 66 + 36 doubles + 4 ints of each record once), 1.1 KB per robot.
+__global__ void __launch_bounds__(256) lmh_summary_kernel(int n, const double *state, const double *out, const int32_t *status, double *summary)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *st = state + (size_t)LMH_STATE_STRIDE * i, *o = out + (size_t)LMH_OUT_STRIDE * i;
+    const int32_t *s = status + LMH_STATUS_STRIDE * i;
+    double *r = summary + (size_t)LMH_SUMMARY_WIDTH * i;
+    double chk = 0.0, tmax = 0.0;
+    for (int k = 0; k < 60; k++) chk += st[k];
+    for (int k = 0; k < 24; k++) tmax = fmax(tmax, fabs(o[k]));
+    for (int k = 0; k < 6; k++) r[k] = st[k];
+    r[6] = st[90]; r[7] = tmax;
+    r[8] = o[24 + 5] + o[24 + 11]; r[9] = o[24 + 5]; r[10] = o[24 + 11];
+    r[11] = (double)s[0]; r[12] = (double)s[1]; r[13] = (double)s[2]; r[14] = (double)__popc((unsigned)s[3]);
+    r[15] = chk;
+}
+extern "C" void lmh_launch_summary(int n, const double *state, const double *out, const int32_t *status, double *summary, hipStream_t s)
+{
+    hipLaunchKernelGGL(lmh_summary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, state, out, status, summary);
 }
 
 // Robot::updateState + getCoM (Robot.cpp:264-269,225-238) for q only.
@@ -2497,7 +2525,8 @@ extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *ou
 {
     // precision 1 (LMH_PRECISION_MIXED): model terms in fp32 arithmetic, references and QP in fp64; the debug kernel is fp64 only
     // LMH_DIAG_NW2=1: the debug kernel on the two-wave schedule (per-wave phase stamps; diagnostics only)
-    if (debug && getenv("LMH_DIAG_NW2")) hipLaunchKernelGGL((lmh_eval_kernel<true, double, 2>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
+    static const bool diag_nw2 = getenv("LMH_DIAG_NW2") != nullptr;     // read once
+    if (debug && diag_nw2) hipLaunchKernelGGL((lmh_eval_kernel<true, double, 2>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
     else if (debug) hipLaunchKernelGGL((lmh_eval_kernel<true, double>), dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
     else if (P->precision == 1) hipLaunchKernelGGL((lmh_eval_kernel<false, float>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
     else hipLaunchKernelGGL((lmh_eval_kernel<false, double>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);

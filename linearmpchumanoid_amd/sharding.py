@@ -20,8 +20,12 @@ def shard_range(total, world, rank):
     return first, base + (1 if rank < rem else 0)
 
 
-def make_summary(state, out, status):
-    """[B,16] f64: final base pose(6) | final t | max|tau| | sum f_z | min f_z R, L | k | qp iters | flags | active count | checksum."""
+def make_summary(state, out, status, ctl=None):
+    """[B,16] f64: final base pose(6) | final t | max|tau| | sum f_z | f_z R, L | k | qp iters | flags | active count | checksum
+    (include/lmh.h lmh_make_summary).  With a controller handle the record is produced by the HIP summary kernel; the torch
+    form below is the same arithmetic for host tensors (gloo rehearsals / CPU tests)."""
+    if ctl is not None and state.is_cuda:
+        return ctl.make_summary(state, out, status)
     B = state.shape[0]
     s = torch.zeros((B, SUMMARY_WIDTH), dtype=torch.float64, device=state.device)
     s[:, 0:6] = state[:, 0:6]
@@ -39,7 +43,7 @@ def make_summary(state, out, status):
     for b in range(32):
         cnt += (mask >> b) & 1
     s[:, 14] = cnt.to(torch.float64)
-    s[:, 15] = state[:, 0:60].sum(dim=1)
+    s[:, 15] = torch.cumsum(state[:, 0:60], dim=1)[:, -1]          # index order, like the kernel
     return s
 
 

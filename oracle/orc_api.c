@@ -263,3 +263,96 @@ void orc_sys_set_segments(void *h, int n_seg, const double *segs, const unsigned
     orc_controller_set_segments(&b->sys.ctl, n_seg, segs, seg_of_sample, xscale);
     b->sys.mpc.zmp_xscale = xscale;
 }
+
+/* controller.hpp:80-124 literals replaced by caller-chosen values (the reference has no setter: they are
+ * in-class initialisers; the C ABI exposes them through lmh_config, so the checker must follow).
+ * g[15] = mu | KpJoints KdJoints KpMom KdMom KpFeet KdFeet | wCoML wCoMK wBasePos wBaseAng wJoints wForce wFoot | epsCoeff.
+ * The friction basis (controller.cpp:33-36) is rebuilt from mu. */
+void orc_sys_set_gains(void *h, const double *g)
+{
+    orc_controller *c = &((orc_box *)h)->sys.ctl;
+    orc_gains *G = &c->gains;
+    G->mu = g[0];
+    G->KpJoints = g[1]; G->KdJoints = g[2]; G->KpMom = g[3]; G->KdMom = g[4]; G->KpFeet = g[5]; G->KdFeet = g[6];
+    G->wCoML = g[7]; G->wCoMK = g[8]; G->wBasePos = g[9]; G->wBaseAng = g[10]; G->wJoints = g[11]; G->wForce = g[12]; G->wFoot = g[13];
+    G->epsCoeff = g[14];
+    const double mu = G->mu;
+    const double fm[12] = {mu, 0, -mu, 0, 0, mu, 0, -mu, 1, 1, 1, 1};
+    memcpy(c->friction, fm, sizeof(fm));
+}
+void orc_sys_get_gains(void *h, double *g)
+{
+    const orc_gains *G = &((orc_box *)h)->sys.ctl.gains;
+    g[0] = G->mu; g[1] = G->KpJoints; g[2] = G->KdJoints; g[3] = G->KpMom; g[4] = G->KdMom; g[5] = G->KpFeet; g[6] = G->KdFeet;
+    g[7] = G->wCoML; g[8] = G->wCoMK; g[9] = G->wBasePos; g[10] = G->wBaseAng; g[11] = G->wJoints; g[12] = G->wForce; g[13] = G->wFoot;
+    g[14] = G->epsCoeff;
+}
+
+/* ---------------- batch driver, general form (CPU baseline of the walking / randomised workloads) ----------------
+ * Same static partition as orc_batch_rollout, but every robot may carry its own reference scale, LIPM height and
+ * raw link table, and the reference set (ZMP samples, support phase, swing segments) is caller supplied. */
+typedef struct {
+    int B, nticks, wbc_calls, n_zmp, n_seg;
+    double dt, t0, horizonT;
+    double *states;                  /* [B][60] in/out */
+    double *out;                     /* [B][36] or NULL */
+    const double *zx, *zy;           /* [n_zmp] */
+    const unsigned char *phase;      /* [n_zmp] or NULL */
+    const double *segs;              /* [n_seg][52] or NULL */
+    const unsigned short *sos;       /* [n_zmp] or NULL */
+    const double *xscale;            /* [B] or NULL */
+    const double *zcom;              /* [B] or [1] (n_zcom) */
+    int n_zcom;
+    const double *raw;               /* [B][28][13] or NULL (nominal) */
+} batch_ex_shared;
+typedef struct { const batch_ex_shared *s; int begin, end; } batch_ex_arg;
+
+static void *batch_ex_worker(void *p)
+{
+    const batch_ex_arg *a = (const batch_ex_arg *)p;
+    const batch_ex_shared *s = a->s;
+    orc_box *b = NULL;
+    for (int i = a->begin; i < a->end; i++) {
+        if (!b || s->raw) {                                       /* a randomised model needs its own Robot (Robot.cpp:14-22) */
+            if (b) orc_sys_destroy(b);
+            b = (orc_box *)orc_sys_create_model(1.0, s->dt, s->horizonT, 0, s->raw ? s->raw + (size_t)i * ORC_NF * 13 : NULL);
+            orc_sys_set_wbc_calls(b, s->wbc_calls, s->wbc_calls > 1);
+            orc_controller_set_refs(&b->sys.ctl, s->n_zmp, s->zx, s->zy, s->phase);
+        }
+        const double z = s->zcom[(s->n_zcom > 1) ? i : 0];
+        orc_sys_set_zcom(b, z);
+        const double xs = s->xscale ? s->xscale[i] : 1.0;
+        if (s->n_seg > 0) orc_sys_set_segments(b, s->n_seg, s->segs, s->sos, xs);
+        else b->sys.mpc.zmp_xscale = xs;
+        memset(b->sys.robot.v, 0, sizeof(b->sys.robot.v));       /* Robot::v_ after construction */
+        double t = s->t0;
+        orc_sys_rollout(b, s->states + (size_t)i * 60, &t, s->dt, s->nticks, NULL, NULL, NULL, NULL);
+        if (s->out) { memcpy(s->out + (size_t)i * 36, b->ev.tau, 24 * sizeof(double)); memcpy(s->out + (size_t)i * 36 + 24, b->ev.f, 12 * sizeof(double)); }
+    }
+    if (b) orc_sys_destroy(b);
+    return NULL;
+}
+
+double orc_batch_rollout_ex(int B, double *states, double *out, double t0, double dt, int nticks, double horizonT,
+                            int n_zmp, const double *zx, const double *zy, const unsigned char *phase,
+                            int n_seg, const double *segs, const unsigned short *sos, const double *xscale,
+                            int n_zcom, const double *zcom, const double *raw, int nthreads, int wbc_calls)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > B) nthreads = B;
+    batch_ex_shared s = {B, nticks, wbc_calls, n_zmp, n_seg, dt, t0, horizonT, states, out, zx, zy, phase, segs, sos, xscale, zcom, n_zcom, raw};
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    batch_ex_arg *args = (batch_ex_arg *)malloc(sizeof(batch_ex_arg) * (size_t)nthreads);
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int k = 0; k < nthreads; k++) {
+        args[k].s = &s;
+        args[k].begin = (int)((long)B * k / nthreads);
+        args[k].end = (int)((long)B * (k + 1) / nthreads);
+        pthread_create(&th[k], NULL, batch_ex_worker, &args[k]);
+    }
+    for (int k = 0; k < nthreads; k++) pthread_join(th[k], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    free(th); free(args);
+    return (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
+}

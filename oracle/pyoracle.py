@@ -37,6 +37,9 @@ def lib():
         _lib.orc_sys_zcom.restype = C.c_double
         _lib.orc_batch_rollout.restype = C.c_double
         _lib.orc_sys_set_zcom.argtypes = [C.c_void_p, C.c_double]
+        _lib.orc_sys_set_gains.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_sys_get_gains.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_batch_rollout_ex.restype = C.c_double
         for name in ("orc_sys_destroy", "orc_sys_mass", "orc_sys_horizon", "orc_sys_zcom", "orc_sys_nzmp"):
             getattr(_lib, name).argtypes = [C.c_void_p]
     return _lib
@@ -110,6 +113,24 @@ class Oracle:
 
     def set_zcom(self, z):
         lib().orc_sys_set_zcom(self._h, C.c_double(z))
+
+    GAIN_FIELDS = ("mu", "kp_joints", "kd_joints", "kp_mom", "kd_mom", "kp_feet", "kd_feet",
+                   "w_com_lin", "w_com_ang", "w_base_pos", "w_base_ang", "w_joints", "w_force", "w_foot", "eps_coeff")
+
+    def gains(self):
+        g = _f64(15)
+        lib().orc_sys_get_gains(self._h, _p(g))
+        return dict(zip(self.GAIN_FIELDS, g.tolist()))
+
+    def set_gains(self, **kw):
+        """controller.hpp:80-124 literals (lmh_config field names); unnamed ones keep their value."""
+        cur = self.gains()
+        for k, v in kw.items():
+            if k not in cur:
+                raise KeyError(k)
+            cur[k] = float(v)
+        g = np.array([cur[k] for k in self.GAIN_FIELDS], dtype=np.float64)
+        lib().orc_sys_set_gains(self._h, _p(g))
 
     def set_segments(self, segs, seg_of_sample, xscale=1.0):
         segs = np.ascontiguousarray(segs, dtype=np.float64)
@@ -207,4 +228,29 @@ def batch_rollout(states, prev_v, t0, dt, nticks, sim_time, horizon_time, zcom, 
     sec = lib().orc_batch_rollout(C.c_int(B), _p(st), _p(pv), _p(out), C.c_double(t0), C.c_double(dt), C.c_int(nticks),
                                   C.c_double(sim_time), C.c_double(horizon_time), C.c_double(zcom),
                                   C.c_int(nthreads), C.c_int(wbc_calls))
+    return sec, st, out
+
+
+def batch_rollout_ex(states, t0, dt, nticks, horizon_time, zmp_x, zmp_y, phase=None, segs=None, seg_of_sample=None,
+                     xscale=None, zcom=0.26, raw_links=None, nthreads=1, wbc_calls=1, lib_override=None):
+    """CPU baseline, general form: B independent closed loops with caller-supplied references (walking / jumping
+    plans), per-instance step length, LIPM height and (optionally) raw link tables.  Returns (seconds, states, out[B,36])."""
+    L = lib_override if lib_override is not None else lib()
+    st = np.ascontiguousarray(states, dtype=np.float64).copy()
+    B = st.shape[0]
+    out = _f64(B, 36)
+    zx = np.ascontiguousarray(zmp_x, dtype=np.float64); zy = np.ascontiguousarray(zmp_y, dtype=np.float64)
+    ph = None if phase is None else np.ascontiguousarray(phase, dtype=np.uint8)
+    sg = None if segs is None else np.ascontiguousarray(segs, dtype=np.float64)
+    so = None if seg_of_sample is None else np.ascontiguousarray(seg_of_sample, dtype=np.uint16)
+    xs = None if xscale is None else np.ascontiguousarray(xscale, dtype=np.float64)
+    zc = np.atleast_1d(np.ascontiguousarray(zcom, dtype=np.float64))
+    raw = None if raw_links is None else np.ascontiguousarray(raw_links, dtype=np.float64)
+    assert xs is None or len(xs) == B
+    assert len(zc) in (1, B) and (raw is None or raw.shape[0] == B)
+    fn = L.orc_batch_rollout_ex
+    fn.restype = C.c_double
+    sec = fn(C.c_int(B), _p(st), _p(out), C.c_double(t0), C.c_double(dt), C.c_int(nticks), C.c_double(horizon_time),
+             C.c_int(len(zx)), _p(zx), _p(zy), _p(ph), C.c_int(0 if sg is None else sg.shape[0]), _p(sg), _p(so), _p(xs),
+             C.c_int(len(zc)), _p(zc), _p(raw), C.c_int(nthreads), C.c_int(wbc_calls))
     return sec, st, out

@@ -125,3 +125,101 @@ def test_jump_plan_schedule():
     assert len(p["phase"]) == n == len(p["zmp_x"]) == len(p["zmp_y"])
     assert (p["phase"][:400] == PHASE_DOUBLE).all() and (p["phase"][400:550] == PHASE_FLIGHT).all() and (p["phase"][550:] == PHASE_DOUBLE).all()
     assert not p["zmp_x"].any() and not p["zmp_y"].any()
+
+
+# --------------------------------------------------------------------------- bench.py entry path (no GPU needed)
+def _bench_mod():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lmh_bench", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m, root
+
+
+def test_bench_defaults_name_the_largest_single_gpu_config():
+    """python bench.py (N = 1) measures BASELINE configs[2]: 4096 robots, walking, N = 32; --gpus N > 1 one GPU's share of configs[3]."""
+    b, _ = _bench_mod()
+    a = b.parse([])
+    assert (a.config, a.instances, a.horizon, a.gpus) == (3, 4096, 32, 1)
+    assert a.ticks * (a.steps + a.warmup) <= 4000 and a.reset_every * a.ticks <= 4000
+    assert (a.steps * a.ticks * a.instances) >= 3_000_000           # >= 0.5 s of timed region at ~6 M ticks/s
+    a8 = b.parse(["--gpus", "8"])
+    assert (a8.config, a8.instances) == (4, 4096)
+    a2 = b.parse(["--config", "2"])
+    assert (a2.instances, a2.horizon, a2.ticks) == (1024, 16, 10)
+    txt = b.WORKLOAD_TEXT[3].format(B=4096, dt=1e-3, N=32)
+    assert "4096" in txt and "walking" in txt and "N=32" in txt
+
+
+def test_bench_gpus_flag_launches_ranks_and_propagates_failure():
+    """`bench.py --gpus 2` with no launcher starts two ranks of itself and fails if a rank fails.  In this container there is
+    no GPU, so both ranks stop at the product's `needs a GPU` assertion: the parent must exit non-zero and print no JSON line.
+    A --gpus that disagrees with WORLD_SIZE is refused before anything is initialised."""
+    import subprocess
+    if torch.cuda.is_available():
+        return                                                      # the GPU form of this test lives in test_gpu_parity.py
+    _, root = _bench_mod()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+    assert "needs a GPU" in r.stderr or "HIP" in r.stderr or "no CPU fallback" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr
+
+
+def test_c_abi_record_files_round_trip_and_match_the_python_format(tmp_path, hip_lib):
+    """lmh_write_summary / lmh_read_summary / lmh_write_log / lmh_read_log (host-only entry points of the C ABI) against
+    linearmpchumanoid_amd.wire: same 64-byte header, same payload, both directions; bad files are refused."""
+    import ctypes as C
+    from linearmpchumanoid_amd import wire
+    from linearmpchumanoid_amd.controller import BatchedController
+    from linearmpchumanoid_amd.capi import LmhError
+    rng = np.random.default_rng(11)
+    s = rng.normal(size=(37, 16)); lg = rng.normal(size=(5, 3, 36))
+    pc, pp = tmp_path / "c.lmhsum", tmp_path / "p.lmhsum"
+    BatchedController.write_summary(pc, s, dt=1e-3)
+    wire.write_summary(pp, s, dt=1e-3)
+    assert pc.read_bytes() == pp.read_bytes()
+    back, dt = BatchedController.read_summary(pp)
+    assert np.array_equal(back, s) and dt == 1e-3
+    lc, lp = tmp_path / "c.lmhlog", tmp_path / "p.lmhlog"
+    BatchedController.write_log(lc, lg, dt=1e-3, t0=0.25)
+    wire.write_log(lp, lg, dt=1e-3, t0=0.25)
+    assert lc.read_bytes() == lp.read_bytes()
+    back, dt, t0 = BatchedController.read_log(lp)
+    assert np.array_equal(back, lg) and (dt, t0) == (1e-3, 0.25)
+    import pytest
+    with pytest.raises(LmhError):
+        BatchedController.read_log(pc)                              # wrong magic
+    pc.write_bytes(pc.read_bytes()[:-8])
+    with pytest.raises(LmhError):
+        BatchedController.read_summary(pc)                          # truncated payload
+    n = C.c_uint64(0)
+    assert hip_lib.lmh_read_summary(str(pp).encode(), back.ctypes.data_as(C.c_void_p), 5, C.byref(n), None) != 0    # buffer too small
+
+
+def test_create_rejects_values_the_kernels_would_divide_by(hip_lib):
+    """lmh_create validates the literals before it touches a device: non-positive weights / mu / eps are LMH_ERR_BAD_ARG
+    (a zero weight is 1/0 in the Woodbury set-up); the defaults pass validation (and then fail with NO_DEVICE here)."""
+    import ctypes as C
+    from linearmpchumanoid_amd.capi import LmhConfig
+    bad = [("w_com_lin", 0.0), ("w_foot", 0.0), ("w_force", -1.0), ("w_joints", 0.0), ("w_base_pos", 0.0), ("w_base_ang", float("nan")),
+           ("mu", 0.0), ("eps_coeff", 0.0), ("w_com_ang", -1.0), ("max_qp_iters", 0), ("precision", 7), ("dt", 0.0), ("gravity", 0.0)]
+    for name, val in bad:
+        cfg = LmhConfig()
+        hip_lib.lmh_config_default(C.byref(cfg))
+        setattr(cfg, name, val)
+        h = C.c_void_p()
+        assert hip_lib.lmh_create(C.byref(cfg), 2, 0, C.byref(h)) == -2, name
+        assert not h.value
+    cfg = LmhConfig()
+    hip_lib.lmh_config_default(C.byref(cfg))
+    cfg.w_com_ang = 50.0; cfg.mu = 0.4; cfg.bpp_rounds = -1
+    h = C.c_void_p()
+    rc = hip_lib.lmh_create(C.byref(cfg), 2, 0, C.byref(h))
+    assert rc == (0 if torch.cuda.is_available() else -1)
+    if h.value:
+        hip_lib.lmh_destroy(h)
