@@ -38,9 +38,14 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # v_mfma_f64_16x16x4_f64: fp64 matrix rate = fp
 MFMA_MOP_FLOP = 512              # SQ_INSTS_VALU_MFMA_MOPS_F64 unit (one 16x16x4 f64 MFMA = 2048 flop = 4 MOPS)
 PROFILE_TAGS = {3: "r02_c3", 2: "r02_c2"}   # profiles/<tag>_rollout_summary.json: PMC passes of the committed kernel
 
+# max_ticks: the tick range in which the closed loop is valid.  Every BASELINE config pairs the 1 kHz control rate with a preview of
+# N <= 48 samples = 16..48 ms (the reference couples the MPC sample time to the control step, mpcLinearPendulum.cpp:43,92), far shorter
+# than the LIPM's unstable time constant sqrt(z/g) = 0.16 s: the loop (which integrates the controller's own acceleration,
+# apps/offline/main.cpp:118-121) drifts out of range after ~0.5-0.6 s, in the CPU oracle exactly as on the GPU (DESIGN.md "Long runs").
+# Rollouts therefore restart from their initial states every max_ticks ticks; restarts inside the timed region are reported.
 DEFAULTS = {2: dict(instances=1024, ticks=10, horizon=16, max_ticks=230),
-            3: dict(instances=4096, ticks=40, horizon=32, max_ticks=4000),
-            4: dict(instances=4096, ticks=40, horizon=32, max_ticks=4000)}
+            3: dict(instances=4096, ticks=40, horizon=32, max_ticks=480),
+            4: dict(instances=4096, ticks=40, horizon=32, max_ticks=480)}
 
 
 def parse(argv=None):
@@ -61,12 +66,15 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--reset-every", type=int, default=None,
                     help="restart the rollouts from the initial states after this many steps; default: as many steps as fit the "
-                         "config's valid tick range (config 3/4: 4000 ticks = BASELINE's run length; config 2: 230 ticks, the pushed loop "
-                         "leaves its valid range ~0.5 s after a 0.3 m/s push, DESIGN.md 'Long runs')")
+                         "config's valid tick range (config 3/4: 480 ticks = settle, DS, SS-R, DS, SS-L of the walking plan; config 2: 230 ticks; "
+                         "see DEFAULTS / DESIGN.md 'Long runs')")
     ap.add_argument("--summary-out", default=None, help="write the gathered end-of-run summary (lmh_write_summary format) to this path")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from rocprofv3 --pmc; default: the committed profiles/ summary when the workload matches it")
-    ap.add_argument("--precision", type=int, default=0, help="lmh_config.precision (0 fp64, 1 mixed, 2 fp32)")
+    ap.add_argument("--step-time", type=float, default=0.2, help="walking: time per step (double + single support) [s]")
+    ap.add_argument("--ds-time", type=float, default=0.05, help="walking: double-support share of a step [s]")
+    ap.add_argument("--settle-time", type=float, default=0.1, help="walking: stance before the first step [s]")
+    ap.add_argument("--precision", type=int, default=0, help="lmh_config.precision (0 fp64, 1 mixed)")
     args = ap.parse_args(argv)
     if args.config is None:
         args.config = 3 if args.gpus == 1 else 4
@@ -160,8 +168,9 @@ def build_workload(args, ctl, first, count, total_ticks):
         host.update(q0=np.tile(q0, (count, 1)), v=v, zcom=np.array([zcom]), zmp_x=zx, zmp_y=zy, phase=None, segs=None, sos=None, xscale=None, raw=None)
         return state, host
     sim_time = total_ticks * args.dt + 0.5
-    n_steps = max(2, int((sim_time - 0.3) / 0.5))
-    plan = trajectories.walk_plan(sim_time, args.dt, num_steps=n_steps, time_per_step=0.5, ds_time=0.1, step_height=0.02, settle_time=0.3)
+    n_steps = max(2, int((sim_time - args.settle_time) / args.step_time))
+    plan = trajectories.walk_plan(sim_time, args.dt, num_steps=n_steps, time_per_step=args.step_time, ds_time=args.ds_time, step_height=0.02,
+                                  settle_time=args.settle_time)
     xs = step_lengths(first, count)
     raw = None
     if args.config == 4:
@@ -423,10 +432,11 @@ def main():
             "metric": "control ticks/s/node (batched NAO WBC+MPC @1kHz)",
             "value": value, "unit": "control ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {0: "f64", 1: "f64 (QP) / f32 (model terms)", 2: "f32 (+1 fp64 refinement step in the QP)"}[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": {0: "f64", 1: "f64 (QP) / f32 (model terms)"}[args.precision], "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.config].format(B=B, dt=args.dt, N=args.horizon), "baseline_config": args.config,
                        "instances_per_gpu": B, "ticks_per_step": args.ticks, "evaluations_per_tick": 4,
-                       "tick_range": [args.warmup * args.ticks, min(n_launch, reset_every) * args.ticks] if n_launch <= reset_every else f"restarts every {reset_every * args.ticks} ticks",
+                       "tick_range": [args.warmup * args.ticks, n_launch * args.ticks] if n_launch <= reset_every
+                       else f"ticks 0..{reset_every * args.ticks} of every rollout, restarted from the initial states every {reset_every} launches (the closed loop leaves its valid range after that)",
                        "qp_start": "cold" if args.cold else "warm", "log": log is not None, "parallelism": f"instances sharded x{world}",
                        "rollout_restarts": (n_launch - 1) // reset_every, "summary_gather_in_timed_region": True},
             "evaluations_per_s": value * 4,
@@ -442,7 +452,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is timed on rank 0 at N = 1 only
             try:
-                g_out = out.cpu().numpy() if n_launch <= reset_every else None
+                # parity sample for the CPU leg: one more (untimed) cycle from the initial states over the same tick range
+                state.copy_(state0); status.zero_()
+                for _ in range(total_ticks // args.ticks):
+                    ctl.rollout(state, args.ticks, out, status, log)
+                torch.cuda.synchronize()
+                g_out = out.cpu().numpy()
                 res["cpu_baseline"] = cpu_baseline(args, host, total_ticks, g_out)
                 if res["cpu_baseline"].get("value"):
                     res["vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]

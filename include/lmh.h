@@ -59,8 +59,6 @@ extern "C" {
 /* arithmetic of the model-term phases (BASELINE config 5 tolerance sweep; build-defined, the reference is fp64 only) */
 #define LMH_PRECISION_FP64 0
 #define LMH_PRECISION_MIXED 1
-#define LMH_PRECISION_FP32 2      /* model terms, references and QP in fp32 arithmetic (push-through cone solve only, one fp64
-                                     residual-refinement step per solve); k = int(t/dt) stays fp64 */
 #define LMH_SUMMARY_WIDTH 16      /* end-of-run summary record (doubles per instance), see lmh_make_summary */
 
 enum {
@@ -86,7 +84,7 @@ typedef struct lmh_config {
     int32_t warm_start;    /* 1: start the active set from the previous evaluation's (same minimiser) */
     int32_t max_qp_iters;
     int32_t precision;     /* LMH_PRECISION_FP64 (reference arithmetic) | LMH_PRECISION_MIXED: model terms (kinematics, C, M, J) in
-                              fp32 arithmetic, references + QP in fp64 | LMH_PRECISION_FP32; k = int(t/dt) is computed in fp64 in every mode */
+                              fp32 arithmetic, references + QP in fp64; k = int(t/dt) is computed in fp64 in every mode */
     int32_t bpp_rounds;    /* block-principal-pivoting rounds of the contact-force QP before the Lawson-Hanson pass takes over:
                               0 = default (10); n > 0 = cap at n rounds; < 0 = skip block pivoting, solve by Lawson-Hanson from the
                               empty set (diagnostic: exercises the finite fall-back) */

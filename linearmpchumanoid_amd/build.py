@@ -4,7 +4,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO = os.path.join(_HERE, "liblmh_hip.so")
+DIAG = os.environ.get("LMH_DIAG") == "1"          # diagnostic build (in-kernel sub-phase stamps): its own file, never the shipped library
+VARIANT = os.environ.get("LMH_VARIANT", "")       # experiment builds: LMH_VARIANT=name[:-DFLAG...] -> liblmh_hip_var_<name>.so (never shipped)
+SO = os.path.join(_HERE, "liblmh_hip_diag.so" if DIAG else ("liblmh_hip_var_%s.so" % VARIANT.split(":")[0] if VARIANT else "liblmh_hip.so"))
 SOURCES = ["lmh_kernels.hip", "lmh_capi.hip"]
 HEADERS = ["lmh_device.h", "lmh_nao_model.h", os.path.join("..", "..", "include", "lmh.h")]
 
@@ -20,10 +22,15 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    diag = ["-DLMH_SUBSTAMPS"] if os.environ.get("LMH_DIAG") == "1" else []      # in-kernel sub-phase stamps (diagnostic build)
+    diag = ["-DLMH_SUBSTAMPS"] if DIAG else []                    # in-kernel sub-phase stamps (diagnostic build)
+    diag += VARIANT.split(":")[1:]
     # iterative-ilp machine scheduler: the kernels run one wave per SIMD, so latency (not register pressure /
     # occupancy) is what the scheduler should optimise; measured +19 % ticks/s over the default strategy.
     sched = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+    # machine LICM off: in the fused rollout loop it hoists ~100 literal constants (libm polynomial coefficients, LDS offsets) into VGPRs
+    # that stay live for the whole launch -> 256 VGPRs + scratch spills; without it the kernel needs 178 VGPRs and no scratch.
+    if os.environ.get("LMH_KEEP_MACHINE_LICM") != "1":
+        sched += ["-mllvm", "-disable-machine-licm"]
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *sched, *diag,
            *[os.path.join(CSRC, f) for f in SOURCES], "-o", SO]
     if verbose:

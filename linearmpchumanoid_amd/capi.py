@@ -7,7 +7,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liblmh_hip.so")
+# LMH_DIAG=1 selects the diagnostic build of the same sources (in-kernel phase stamps, scripts/gpu_phase_stamps.py)
+# LMH_VARIANT=name selects an experiment build (linearmpchumanoid_amd/build.py); neither is the shipped library
+_VAR = os.environ.get("LMH_VARIANT", "").split(":")[0]
+SO_PATH = os.path.join(_HERE, "liblmh_hip_diag.so" if os.environ.get("LMH_DIAG") == "1" else ("liblmh_hip_var_%s.so" % _VAR if _VAR else "liblmh_hip.so"))
 
 STATE_STRIDE = 96
 OUT_STRIDE = 80
@@ -22,7 +25,7 @@ FLAG_ZMP_RANGE = 4
 FLAG_NOT_SPD = 8
 
 PHASE_DOUBLE, PHASE_RIGHT, PHASE_LEFT, PHASE_FLIGHT = 0, 1, 2, 3
-PRECISION_FP64, PRECISION_MIXED, PRECISION_FP32 = 0, 1, 2   # lmh_config.precision (include/lmh.h)
+PRECISION_FP64, PRECISION_MIXED = 0, 1   # lmh_config.precision (include/lmh.h)
 SUMMARY_WIDTH = 16
 
 # every symbol include/lmh.h declares (checked by tests/test_abi.py)

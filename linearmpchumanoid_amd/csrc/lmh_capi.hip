@@ -14,7 +14,7 @@
 #include "lmh_nao_model.h"
 
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s);
-extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
+extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s);
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s);
 extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const LmhIkTarget *target, int32_t *iters, hipStream_t s);
@@ -38,6 +38,9 @@ struct lmh_handle {
     std::vector<double> h_state, h_out, h_gain;
     std::vector<int32_t> h_status;
     LmhDevParams P;
+    LmhDevParams *d_P = nullptr;      // device copy read by the rollout kernel
+    LmhDevParams P_dev;               // what d_P currently holds
+    bool P_dev_valid = false;
 };
 
 extern "C" const char *lmh_last_error(void) { return g_err.c_str(); }
@@ -259,8 +262,8 @@ static const char *validate_config(const lmh_config *c)
     const double g[6] = {c->kp_joints, c->kd_joints, c->kp_mom, c->kd_mom, c->kp_feet, c->kd_feet};
     for (double v : g) if (!std::isfinite(v)) return "PD gains must be finite";
     if (c->max_qp_iters < 1) return "max_qp_iters must be >= 1";
-    if (c->precision != LMH_PRECISION_FP64 && c->precision != LMH_PRECISION_MIXED && c->precision != LMH_PRECISION_FP32)
-        return "precision must be LMH_PRECISION_FP64, LMH_PRECISION_MIXED or LMH_PRECISION_FP32";
+    if (c->precision != LMH_PRECISION_FP64 && c->precision != LMH_PRECISION_MIXED)
+        return "precision must be LMH_PRECISION_FP64 or LMH_PRECISION_MIXED";
     return nullptr;
 }
 
@@ -316,7 +319,7 @@ extern "C" int lmh_destroy(lmh_handle *h)
     if (!h) return LMH_OK;
     (void)hipSetDevice(h->device);
     void *bufs[] = {h->d_model, h->d_mpc, h->d_zx, h->d_zy, h->d_gcol, h->d_raw, h->d_phase, h->d_state, h->d_out, h->d_status,
-                    h->d_segs, h->d_xscale, h->d_sos};
+                    h->d_segs, h->d_xscale, h->d_sos, h->d_P};
     for (void *b : bufs) if (b) (void)hipFree(b);
     delete h;
     return LMH_OK;
@@ -479,7 +482,13 @@ extern "C" int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_
     if (!d_state || !d_out || !d_status || n_ticks < 0) return fail(LMH_ERR_BAD_ARG, "bad argument");
     if (n_ticks == 0) return LMH_OK;
     HIPCHK(hipSetDevice(h->device));
-    lmh_launch_rollout(&h->P, d_state, d_out, d_status, d_log, n_ticks, (hipStream_t)stream);
+    if (!h->d_P) HIPCHK(hipMalloc(&h->d_P, sizeof(LmhDevParams)));
+    if (!h->P_dev_valid || std::memcmp(&h->P_dev, &h->P, sizeof(LmhDevParams)) != 0) {   // set-up calls changed the block since the last launch
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));          // an earlier launch on this stream may still read the old copy
+        HIPCHK(hipMemcpy(h->d_P, &h->P, sizeof(LmhDevParams), hipMemcpyHostToDevice));
+        std::memcpy(&h->P_dev, &h->P, sizeof(LmhDevParams)); h->P_dev_valid = true;
+    }
+    lmh_launch_rollout(&h->P, h->d_P, d_state, d_out, d_status, d_log, n_ticks, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return LMH_OK;
 }

@@ -170,9 +170,12 @@ __device__ __forceinline__ int lane_opaque()
 __shared__ double *g_dbg;
 #define SUBSTAMP(i) do { if (g_dbg && LANE == 0) g_dbg[3900 + (i)] = (double)clock64(); } while (0)
 #define SET_GDBG(p) do { if (LANE == 0) g_dbg = (p); } while (0)
+// per-wave timeline (two-wave debug kernel): wave w stamps slot 3700 + 100 w + i (scripts/gpu_wave_timeline.py)
+#define WSTAMP(i) do { if (g_dbg && LANE == 0) g_dbg[3700 + 100 * (int)(threadIdx.x >> 6) + (i)] = (double)clock64(); } while (0)
 #else
 #define SUBSTAMP(i) do { } while (0)
 #define SET_GDBG(p) do { } while (0)
+#define WSTAMP(i) do { } while (0)
 #endif
 
 // ---- LDS views with a working precision R.  The model-term phases (kinematics, Newton-Euler, CRBA, Jacobian) are
@@ -370,7 +373,8 @@ __device__ __forceinline__ void ldl16_backward(double (&b)[M], unsigned live, in
 {
     if constexpr (J > 0) {
         if ((live >> J) & 1u) {
-            const double nl = (lane < J) ? -Ls[J * (N + 1) + lane] : 0.0;
+            const double lv = Ls[J * (N + 1) + ((lane < N) ? lane : 0)];      // unconditional load (clamped), masked by value: no exec branch
+            const double nl = (lane < J) ? -lv : 0.0;
             dpp_fmac_rhs<J>(b, nl);
         }
         ldl16_backward<J - 1, N>(b, live, lane, Ls);
@@ -479,17 +483,21 @@ __device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], un
     int bad = 0;
     double myinv = 0.0;                                           // 1 / d_lane (0 on rows that are not live)
     if constexpr (N <= 16) {
+        WSTAMP(40);
         ldl16_forward<0>(a, b, live, lane, bad, myinv);
         bad = __builtin_amdgcn_readfirstlane(bad);
 #pragma unroll
         for (int r = 0; r < M; r++) b[r] *= myinv;                // w = D^-1 z
+        WSTAMP(41);
         WSYNC();
         if (lane < N) {
 #pragma unroll
             for (int c = 0; c < N - 1; c++) Ls[lane * (N + 1) + c] = a[c];          // L[lane][c], c < lane
         }
         WSYNC();
+        WSTAMP(42);
         ldl16_backward<N - 1, N>(b, live, lane, Ls);
+        WSTAMP(43);
         return bad;
     }
 #pragma unroll
@@ -523,6 +531,74 @@ __device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], un
         for (int r = 0; r < M; r++) b[r] = fma(-lji, bcast_lane(b[r], j), b[r]);
     }
     return bad;
+}
+
+// ---- Gauss-Jordan form of the register-resident SPD solve for N <= 16 (the well-conditioned systems of the QP set-up: Woodbury core,
+// Schur complement, push-through system, K_f).  Lane i < N holds the FULL row i in a[]; pivot J eliminates column J from every other
+// row, rows above the pivot included: a[c] += bcast16<J>(a[c]) * nf, b[r] += bcast16<J>(b[r]) * nf with nf = -a_iJ / d_J (0 on row J) --
+// every register broadcasts its own lane-J entry, one v_fmac_f64_dpp each.  The instruction count per pivot equals the LDL' forward
+// step's, and there is no backward substitution, no L parked in LDS and no fence: x_i = b_i / d_i at the end.  Without pivoting this is
+// as accurate as LDL' on an SPD matrix (measured on the Woodbury core: 7e-14 both, condition 1e4).
+#define LMH_GS8(J) LMH_FS(0, 8, 9) LMH_FS(1, 8, 9) LMH_FS(2, 8, 9) LMH_FS(3, 8, 9) LMH_FS(4, 8, 9) LMH_FS(5, 8, 9) LMH_FS(6, 8, 9) LMH_FS(7, 8, 9)
+template <int C0, int CNT, int J, int N>
+__device__ __forceinline__ void dpp_fmac_self(double (&a)[N], double m)         // a[c] += bcast16<J>(a[c]) * m for c in [C0, C0 + CNT)
+{
+    if constexpr (CNT >= 8) {
+        asm volatile("s_nop 1\n\t" LMH_GS8(J)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]), "+v"(a[C0 + 4]), "+v"(a[C0 + 5]), "+v"(a[C0 + 6]), "+v"(a[C0 + 7])
+                     : "v"(m), "n"(J));
+        dpp_fmac_self<C0 + 8, CNT - 8, J>(a, m);
+    } else if constexpr (CNT == 7) {
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 7, 8) LMH_FS(1, 7, 8) LMH_FS(2, 7, 8) LMH_FS(3, 7, 8) LMH_FS(4, 7, 8) LMH_FS(5, 7, 8) LMH_FS(6, 7, 8)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]), "+v"(a[C0 + 4]), "+v"(a[C0 + 5]), "+v"(a[C0 + 6]) : "v"(m), "n"(J));
+    } else if constexpr (CNT == 6) {
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 6, 7) LMH_FS(1, 6, 7) LMH_FS(2, 6, 7) LMH_FS(3, 6, 7) LMH_FS(4, 6, 7) LMH_FS(5, 6, 7)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]), "+v"(a[C0 + 4]), "+v"(a[C0 + 5]) : "v"(m), "n"(J));
+    } else if constexpr (CNT == 5) {
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 5, 6) LMH_FS(1, 5, 6) LMH_FS(2, 5, 6) LMH_FS(3, 5, 6) LMH_FS(4, 5, 6)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]), "+v"(a[C0 + 4]) : "v"(m), "n"(J));
+    } else if constexpr (CNT == 4) {
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 4, 5) LMH_FS(1, 4, 5) LMH_FS(2, 4, 5) LMH_FS(3, 4, 5)
+                     : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]) : "v"(m), "n"(J));
+    } else if constexpr (CNT == 3) {
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 3, 4) LMH_FS(1, 3, 4) LMH_FS(2, 3, 4) : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]) : "v"(m), "n"(J));
+    } else if constexpr (CNT == 2) {
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 2, 3) LMH_FS(1, 2, 3) : "+v"(a[C0]), "+v"(a[C0 + 1]) : "v"(m), "n"(J));
+    } else if constexpr (CNT == 1) {
+        asm volatile("s_nop 1\n\t" LMH_FS(0, 1, 2) : "+v"(a[C0]) : "v"(m), "n"(J));
+    }
+}
+// one pivot, then the next.  ROWS = number of 16-lane DPP rows that carry an independent system (1: lanes 0..15; 2: the two feet of
+// kinv_compute); `rowon` switches a whole system off (its pivots are replaced by 1).
+template <int J, int N, int M>
+__device__ __forceinline__ void gj16_step(double (&a)[N], double (&b)[M], unsigned live, int l16, bool rowon, double dmin, int &bad, double &myinv)
+{
+    if constexpr (J < N) {
+        if ((live >> J) & 1u) {                                   // wave-uniform
+            double d = bcast16<J>(a[J]);
+            if (rowon && !(d > dmin)) bad = 1;
+            d = (rowon && d > dmin) ? d : 1.0;
+            const double invd = fast_rcp(d);
+            const double nf = (l16 == J) ? 0.0 : -(a[J] * invd);
+            if (l16 == J) myinv = invd;
+            dpp_fmac_self<J + 1, N - 1 - J, J>(a, nf);
+            dpp_fmac_self<0, M, J>(b, nf);
+        }
+        gj16_step<J + 1>(a, b, live, l16, rowon, dmin, bad, myinv);
+    }
+}
+// On exit b[r] of lane i < N holds x_i.  Returns non-zero (wave-uniform) if a pivot was not positive.
+template <int N, int M>
+__device__ __forceinline__ int gj_solve_regs(double (&a)[N], double (&b)[M], unsigned live)
+{
+    static_assert(N <= 16, "one DPP row");
+    const int lane = LANE;
+    int bad = 0;
+    double myinv = 0.0;
+    gj16_step<0>(a, b, live, lane, lane < 16, 0.0, bad, myinv);
+#pragma unroll
+    for (int r = 0; r < M; r++) b[r] *= myinv;
+    return (__ballot(bad != 0) != 0ull) ? 1 : 0;
 }
 
 
@@ -1458,6 +1534,7 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
     const unsigned FR = F & 0xFFFFu, FL = F >> 16;
     const bool useR = FR != 0u, useL = FL != 0u;
     double *K = scr, *Ki = Kdst, *Ls = scr + 72;
+    (void)Ls;
     WSYNC();
     {   // K_f = G diag(free_f) G' for both feet as ONE 16 x 16 x 16 matrix-core product: row block f of A carries foot f's
         // mask, so the two diagonal 6 x 6 blocks of the tile are K_R and K_L (the off-diagonal blocks are not used)
@@ -1479,6 +1556,16 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
         const bool rowon = (row == 0 && useR) || (row == 1 && useL);
         const bool on = rowon && l16 < 6;
         const int rb = (row < 2) ? 36 * row : 0, lr = (l16 < 6) ? l16 : 0;
+#ifndef LMH_LDL_KINV
+        double a[6], bb[6], myinv = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { a[c] = K[rb + 6 * lr + c]; bb[c] = (l16 == c) ? 1.0 : 0.0; }      // full rows (Gauss-Jordan), both feet at once
+        // K_f entries are O(1e-3 .. 10); a rank-deficient block pivots at ~1e-17
+        gj16_step<0>(a, bb, 0x3Fu, l16, rowon, 1e-12, bad, myinv);
+#pragma unroll
+        for (int c = 0; c < 6; c++) bb[c] *= myinv;
+        if (row < 2 && l16 < 6) {
+#else
         double a[6], bb[6], myinv = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; c++) { a[c] = (on && c <= l16) ? K[rb + 6 * lr + c] : 0.0; bb[c] = (on && l16 == c) ? 1.0 : 0.0; }
@@ -1493,6 +1580,7 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
         WSYNC();
         ldl6_pair_back<5>(bb, l16, Ls + ((row < 2) ? 42 * row : 0));
         if (row < 2 && l16 < 6) {
+#endif
 #pragma unroll
             for (int c = 0; c < 6; c++) Ki[36 * row + 6 * l16 + c] = on ? bb[c] : 0.0;       // K_f^-1 (symmetric); 0 for a foot without force
         }
@@ -1512,6 +1600,20 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
     if (have_ki == 0 && kinv_compute(L, F, L + C_LS + 72, L + C_LS + 240)) return 0;     // wave-uniform: some K_f is singular
     WSYNC();
     {   // (W + eps K^-1) w = h on the rows of the feet that carry force
+#ifndef LMH_LDL_PT
+        double a[12], b[1];
+        const int lr = (lane < 12) ? lane : 0, fi = lr / 6, ri = lr % 6;
+        const bool rowuse = (lane < 12) && ((fi == 0) ? useR : useL);
+        const double eps = P.eps_coeff;
+#pragma unroll
+        for (int c = 0; c < 12; c++) {                             // full rows, unconditional loads: rows / columns of a foot without force are
+            const double g = Ki[36 * fi + 6 * ri + c % 6];         // never pivots (live mask), so their entries are don't-cares
+            a[c] = L[P_W + 12 * lr + c] + ((c / 6 == fi) ? eps * g : 0.0);
+        }
+        b[0] = L[P_H12 + lr];
+        const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
+        if (gj_solve_regs<12, 1>(a, b, live)) *flags |= LMH_FLAG_NOT_SPD;
+#else
         double a[12], b[1];
         const int fi = lane / 6, ri = lane % 6;
         const bool rowuse = (lane < 12) && ((fi == 0) ? useR : useL);
@@ -1528,6 +1630,7 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
         b[0] = rowuse ? L[P_H12 + lane] : 0.0;
         const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
         if (ldl_solve_regs<12, 1>(a, b, live, Ls)) *flags |= LMH_FLAG_NOT_SPD;
+#endif
         WSYNC();
         if (lane < 12) Yv[lane] = rowuse ? b[0] : 0.0;             // w
     }
@@ -1572,8 +1675,10 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
     int flags = 0, it = 0;
     forced = (unsigned)__builtin_amdgcn_readfirstlane((int)forced);
     unsigned F = (unsigned)__builtin_amdgcn_readfirstlane((int)(*F_io & ~forced));    // scalar from here on (ballots keep it so)
+    WSTAMP(30);
     double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
     qmax = wave_max(qmax);
+    WSTAMP(31);
     const double toll = 1e-14 * (1.0 + qmax);                    // ~10x the round-off of (P c - q): a looser bound lets a warm start keep a coefficient
                                                                    // out whose multiplier is slightly negative (1e-6 relative error in tau after a contact switch)
     const bool mine = (lane < 32) && !((forced >> lane) & 1u);
@@ -1589,6 +1694,21 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         // (W + eps (G G')^-1) w = h and c = G'(G G')^-1 w  (push-through identity; G G' is constant,
         // block diagonal and well conditioned) -- 12 pivots instead of 32.
         it++;
+#ifndef LMH_LDL_AF
+        double a[12], b[1];
+        {
+            const int lr = (lane < 12) ? lane : 0, fi = lr / 6, ri = lr % 6;
+            const double eps = P.eps_coeff;
+#pragma unroll
+            for (int c = 0; c < 12; c++) {                         // full rows, unconditional loads (Gauss-Jordan)
+                const double g = L[P_GI6 + 6 * ri + c % 6];
+                a[c] = L[P_W + 12 * lr + c] + ((c / 6 == fi) ? eps * g : 0.0);
+            }
+            b[0] = L[P_H12 + lr];
+        }
+        WSTAMP(32);
+        if (gj_solve_regs<12, 1>(a, b, 0xFFFu)) flags |= LMH_FLAG_NOT_SPD;
+#else
         double a[12], b[1];
         {
             const int fi = lane / 6, ri = lane % 6;
@@ -1604,6 +1724,8 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
             b[0] = (lane < 12) ? L[P_H12 + lane] : 0.0;
         }
         if (ldl_solve_regs<12, 1>(a, b, 0xFFFu, L + C_LS)) flags |= LMH_FLAG_NOT_SPD;
+#endif
+        WSTAMP(33);
         WSYNC();
         if (lane < 12) L[P_U12 + lane] = b[0];
         WSYNC();
@@ -1613,8 +1735,10 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
 #pragma unroll
             for (int k = 0; k < 6; k++) zj += gp[k] * u[k];
         }
+        WSTAMP(34);
         const double cmax = wave_max(fabs(zj));
         const unsigned bad = (unsigned)__ballot(lane < 32 && zj < -1e-10 * (1.0 + cmax));
+        WSTAMP(35);
         cj = zj;
         if (bad == 0u) {
             WSYNC();
@@ -1627,6 +1751,9 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         F ^= bad;
     }
     for (;;) {
+#ifndef LMH_OLD_CAP
+        if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }    // no further solve is started once the cap is reached
+#endif
         it++;
         double zj;
         if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
@@ -1682,7 +1809,9 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
                 F &= ~dm;
             }
         }
+#ifdef LMH_OLD_CAP
         if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
+#endif
     }
     WSYNC();
     if (lane < 32) L[P_CC + lane] = ((F >> lane) & 1u) ? cj : 0.0;
@@ -1722,7 +1851,9 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
         L[B_BP + e] = (cidx == 0) ? -L[P_QREF + i] : L[P_MTOP + 30 * (cidx - 1) + i] * iDi;
     }
+    WSTAMP(10);
     bsync<NW>();
+    WSTAMP(11);
     if (dbgp && LANE == 0) dbgp[4070] = (double)clock64();
     // ---- Cm = Om^-1 + U D^-1 U'  and  V = U bp'  on the matrix cores (K = 30 padded to 32)
     const int ld = 19;
@@ -1763,7 +1894,9 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
             if (do_cm && row < nU && tr < nU) L[B_CF + 18 * row + tr] = cm[g] + ((row == tr) ? L[B_OB + 18 + row] : 0.0);   // full copy for Cm ob
         }
     }
+    WSTAMP(12);
     bsync<NW>();
+    WSTAMP(13);
     if (wid == 0) {                                                // wave 0: right-hand side fix-up and the nU x nU factorisation
     if (lane < nU) {                                               // V_g += Cm ob - beta
         double sacc = -L[B_OB + 36 + lane];
@@ -1775,15 +1908,29 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         L[B_K + ld * nU + lane] += sacc;
     }
     WSYNC();
+    WSTAMP(14);
     if (dbgp && LANE == 0) dbgp[4073] = (double)clock64();
-    {   // Cm t = V for the 7 right-hand sides: row-per-lane register LDL'
+    {   // Cm t = V for the 7 right-hand sides, row per lane in registers
         double a[NU], bb[7];
         const bool on = lane < nU;
+#ifdef LMH_LDL_WB
+        if constexpr (false) {
+#else
+        if constexpr (NU <= 16) {                                  // Gauss-Jordan on full rows
+#endif (B_CF is the full symmetric copy): no masked loads
+            const int lr = on ? lane : 0;
 #pragma unroll
-        for (int c = 0; c < NU; c++) a[c] = (on && c <= lane) ? L[B_K + ld * lane + c] : 0.0;
+            for (int c = 0; c < NU; c++) a[c] = L[B_CF + 18 * lr + c];
 #pragma unroll
-        for (int r = 0; r < 7; r++) bb[r] = on ? L[B_K + ld * (nU + r) + lane] : 0.0;
-        if (ldl_solve_regs<NU, 7>(a, bb, (1u << NU) - 1u, L + B_LS)) flags |= LMH_FLAG_NOT_SPD;
+            for (int r = 0; r < 7; r++) bb[r] = L[B_K + ld * (nU + r) + lr];
+            if (gj_solve_regs<NU, 7>(a, bb, (1u << NU) - 1u)) flags |= LMH_FLAG_NOT_SPD;
+        } else {
+#pragma unroll
+            for (int c = 0; c < NU; c++) a[c] = (on && c <= lane) ? L[B_K + ld * lane + c] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 7; r++) bb[r] = on ? L[B_K + ld * (nU + r) + lane] : 0.0;
+            if (ldl_solve_regs<NU, 7>(a, bb, (1u << NU) - 1u, L + B_LS)) flags |= LMH_FLAG_NOT_SPD;
+        }
         if (on) {
             bb[0] -= L[B_OB + lane];                               // t' = t_g - ob in column 0
 #pragma unroll
@@ -1791,7 +1938,9 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         }
     }
     }
+    WSTAMP(15);
     bsync<NW>();
+    WSTAMP(16);
     if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
     // ---- Y = bp' - D^-1 U' t'   (30 x 7; two row tiles, K = nU padded to 20)
     {
@@ -1808,7 +1957,9 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
             }
         }
     }
+    WSTAMP(17);
     bsync<NW>();
+    WSTAMP(18);
     if (dbgp && LANE == 0) dbgp[4010] = (double)clock64();
     // ---- S = Mb Y_M (6x6), d = C_b - Mb Y_g  (one tile, K = 30 padded to 32); Si = S^-1
     if (wid == 0) {                                                // a dependent chain of small products: wave 0
@@ -1824,10 +1975,14 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         }
     }
     WSYNC();
+    WSTAMP(19);
     {   // Si = S^-1: six unit right-hand sides
+        // S is only moderately conditioned as far as LDL' is concerned, but Gauss-Jordan loses ~cond(S) more digits and leaves S^-1 (hence W)
+        // unsymmetric at the 1e-10 level, which the active-set tests of the cone QP (tolerances ~1e-14) do not survive: LDL' here.
         double a[6], bb[6];
+        const int lr = (lane < 6) ? lane : 0;
 #pragma unroll
-        for (int c = 0; c < 6; c++) { a[c] = (lane < 6 && c <= lane) ? L[B_S + 7 * lane + c] : 0.0; bb[c] = (lane == c) ? 1.0 : 0.0; }
+        for (int c = 0; c < 6; c++) { const double sv = L[B_S + 7 * lr + c]; a[c] = (lane < 6 && c <= lane) ? sv : 0.0; bb[c] = (lane == c) ? 1.0 : 0.0; }
         if (ldl_solve_regs<6, 6>(a, bb, 0x3Fu, L + B_LS)) flags |= LMH_FLAG_NOT_SPD;
         if (lane < 6) {
 #pragma unroll
@@ -1835,6 +1990,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         }
     }
     WSYNC();
+    WSTAMP(20);
     // ---- T1 = Jb Si (12x6);  [W | h] = [w_force I + T1 Jb' | T1 d]   (K = 6 padded to 8)
     {
         auto a_jb = [=](int m, int k) { const bool ok = m < 12 && k < 6; const double v = jdense(L, ok ? m : 0, ok ? k : 0); return ok ? v : 0.0; };
@@ -1844,6 +2000,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         for (int g = 0; g < 4; g++) { const int row = tq + 4 * g; if (row < 12 && tr < 6) L[B_T1 + 6 * row + tr] = t1[g]; }
     }
     WSYNC();
+    WSTAMP(21);
     {
         auto a_t1 = [=](int m, int k) { return ldz(L, m < 12 && k < 6, B_T1 + 6 * m + k, B_T1); };
         auto b_jd = [=](int k, int n) { const bool kin = k < 6; const double vj = jdense(L, (n < 12) ? n : 0, kin ? k : 0); const double vd = L[P_D6 + (kin ? k : 0)]; return !kin ? 0.0 : (n < 12) ? vj : (n == 12) ? vd : 0.0; };
@@ -1856,6 +2013,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         }
     }
     }
+    WSTAMP(22);
     if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
     // ---- qv = G' h (the cone Hessian G'WG + eps I itself is only formed if the general free-set solve is needed,
     //      build_cone_matrix); G[k][j] is the generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
@@ -1869,6 +2027,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         }
         WSYNC();
     }
+    WSTAMP(23);
     return flags;
 }
 
@@ -1878,7 +2037,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
 {
     const int lane = LANE;
     int flags = (P.w_com_ang == 0.0) ? qp_setup<15, NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
-    if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }            // the active-set iteration and the recovery are sequential: wave 0;
+    if (NW == 2 && wid != 0) { WSTAMP(26); bsync<NW>(); WSTAMP(27); return 0; }            // the active-set iteration and the recovery are sequential: wave 0;
                                                                    // the helper waits for the free set it will prepare K^-1 for
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
     // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
@@ -1887,8 +2046,10 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     if (ph == LMH_PHASE_RIGHT || ph == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
     unsigned F = (P.warm_start ? *Fmask_io : 0xFFFFFFFFu) & ~forced;
     int it = 0;
+    WSTAMP(24);
     flags |= cone_qp(L, P, forced, &F, &it, dbgp);
     WSYNC();
+    WSTAMP(25);
     *Fmask_io = F;
     *iters_out = it;
     if (lane == 0) L[P_KF] = (double)F;                            // published for the helper wave (next evaluation's warm start)
@@ -1918,7 +2079,9 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         L[P_A + lane] = -s;
     }
     WSYNC();
+    WSTAMP(26);
     bsync<NW>();                                                   // the helper wave takes over from here: torques, then K^-1 and references of the next evaluation
+    WSTAMP(27);
     return flags;
 }
 
@@ -1973,6 +2136,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
 #define STAMP(i) do { if (dbg && LANE == 0) dbg[(wid ? 3950 : 4000) + (i)] = (double)clock64(); } while (0)   // wave 1 (diagnostic two-wave debug kernel): 3950..
     STAMP(0);
+    WSTAMP(0);
     const RefPrefetch pre = prefetch_refs(P, inst, t);
     if (NW == 2 && wid == 1) {
         // while wave 0 runs the forward kinematics: K_f^-1 of the free set the cone solve will start from (same rule as
@@ -1993,10 +2157,14 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         WSYNC();
     }
     if (wid == 0) phase_fk<R>(L, P.gcol + 228);
+    WSTAMP(1);
     bsync<NW>();
+    WSTAMP(2);
     STAMP(1);
     phase_com_x<NW, R>(L, wid);
+    WSTAMP(3);
     bsync<NW>();
+    WSTAMP(4);
     STAMP(2);
     if (dbg) {
         for (int e = LANE; e < 336; e += 64) dbg[e] = L[A_T + e];
@@ -2015,15 +2183,20 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         else phase_crba<R>(L);
         STAMP(5);                                                  // per wave: end of its share of the tree phases
     }
+    WSTAMP(5);
     bsync<NW>();
+    WSTAMP(6);
     STAMP(6);
     flags |= phase_refs<NW>(L, P, inst, t, pre, wid, k_out, &ph);
+    WSTAMP(7);
     bsync<NW>();
+    WSTAMP(8);
     STAMP(7);
     flags |= phase_qp<NW>(L, P, ph, wid, Fmask, iters_out, dbg);
     STAMP(8);
     if constexpr (NW == 1) { phase_outputs_tau(L); phase_outputs_qdd(L); }
     else { if (wid == 0) phase_outputs_qdd(L); else phase_outputs_tau(L); }
+    WSTAMP(28);
     STAMP(9);
     if (dbg) {
         const int lane = LANE;
@@ -2143,11 +2316,24 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, doubl
 // kernel is held to 256 registers.  Wave 0 owns the RK4 state (lane i < 60 <-> component i) and everything
 // sequential; wave 1 joins for the phases controller_eval<2> splits.
 template <typename R>
-__global__ void __launch_bounds__(LMH_ROLLOUT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *log, int n_ticks)
+#ifndef LMH_ROLLOUT_ATTR
+#define LMH_ROLLOUT_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+__global__ void __launch_bounds__(LMH_ROLLOUT_THREADS) LMH_ROLLOUT_ATTR
+#ifdef LMH_PARAM_BYVAL
+lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg_unused, LmhDevParams Pv, double *state, double *out, int32_t *status, double *log, int n_ticks)
 {
+    const LmhDevParams *Pg = &Pv;
+#else
+lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, double *state, double *out, int32_t *status, double *log, int n_ticks)
+{
+#endif
+    // The parameter block is read through a pointer that is made opaque once per evaluation (params_of): hoisting its ~70 scalars out
+    // of the tick loop pins them in SGPRs for the whole launch (round 1: 189 SGPR + 16 VGPR spills, 60 B of scratch per lane that reached
+    // HBM); re-reading them costs a few scalar-cache loads per evaluation.
     __shared__ double L[LDS_DOUBLES];
     const int inst = blockIdx.x;
+    const LmhDevParams &P = *Pg;
     if (inst >= P.n_instances) return;                             // workgroup-uniform
     const int lane = LANE;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2182,7 +2368,11 @@ lmh_rollout_kernel(LmhDevParams P, double *state, double *out, int32_t *status, 
                 if (lane < 60) L[P_Q + lane] = xs;
                 WSYNC();
             }
-            flags |= controller_eval<2, R>(L, P, inst, ts, wid, &F, &k, &iters, nullptr);
+            const LmhDevParams *Pe = Pg;
+#ifndef LMH_PARAM_BYVAL
+            asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
+#endif
+            flags |= controller_eval<2, R>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
                 // xdot (apps/offline/main.cpp:107-121)
@@ -2531,10 +2721,11 @@ extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *ou
     else if (P->precision == 1) hipLaunchKernelGGL((lmh_eval_kernel<false, float>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
     else hipLaunchKernelGGL((lmh_eval_kernel<false, double>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
 }
-extern "C" void lmh_launch_rollout(const LmhDevParams *P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
+// d_P: device copy of *P (the rollout kernel reads its parameters through a pointer, see lmh_rollout_kernel)
+extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
 {
-    if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, log, n_ticks);
-    else hipLaunchKernelGGL(lmh_rollout_kernel<double>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, log, n_ticks);
+    if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
+    else hipLaunchKernelGGL(lmh_rollout_kernel<double>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
 }
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s)
 {

@@ -142,7 +142,7 @@ def test_bench_defaults_name_the_largest_single_gpu_config():
     b, _ = _bench_mod()
     a = b.parse([])
     assert (a.config, a.instances, a.horizon, a.gpus) == (3, 4096, 32, 1)
-    assert a.ticks * (a.steps + a.warmup) <= 4000 and a.reset_every * a.ticks <= 4000
+    assert a.reset_every * a.ticks <= 480                          # the walking loop's valid range (bench.DEFAULTS)
     assert (a.steps * a.ticks * a.instances) >= 3_000_000           # >= 0.5 s of timed region at ~6 M ticks/s
     a8 = b.parse(["--gpus", "8"])
     assert (a8.config, a8.instances) == (4, 4096)
