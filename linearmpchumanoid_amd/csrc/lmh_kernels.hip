@@ -41,10 +41,22 @@
 // evaluation (Newton-Euler | CRBA, the two reference chains, the MFMA tiles of the QP set-up) run side by side
 // and join at workgroup barriers; the sequential factorisations stay on wave 0.  NW = 1 (the evaluation, IK and
 // model kernels) degenerates to the single-wave schedule: the join is the wave fence.
+#ifdef LMH_SUBSTAMPS
+__shared__ long long g_bwait[2];     // diagnostic build: cycles each wave of the robot has spent inside workgroup barriers
+#endif
 template <int NW>
 __device__ __forceinline__ void bsync()
 {
-    if constexpr (NW == 1) WSYNC(); else __syncthreads();
+    if constexpr (NW == 1) WSYNC();
+    else {
+#ifdef LMH_SUBSTAMPS
+        const long long t0 = clock64();
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 0) g_bwait[threadIdx.x >> 6] += clock64() - t0;
+#else
+        __syncthreads();
+#endif
+    }
 }
 
 // ------------------------------------------------------------------ constant tables
@@ -107,7 +119,7 @@ enum {
     P_C = 672, P_CG = 702, P_AGPQP = 708, P_JPQP = 714, P_COM = 726, P_COMV = 729, P_ANGM = 732, P_MPC = 735,
     P_MTOP = 744, P_HL = 924, P_JC = 1068, P_AG = 1212,
     P_QREF = 1392, P_HREF = 1422, P_FREF = 1428, P_VFOOT = 1440,
-    P_Y = 1452,       // 30 x 7 : H^-1 [g | Mb']
+    P_YT = 1452,      // 7 x 30 : (H^-1 [g | Mb'])' -- row n holds column n (the recovery reads YT[n][lane])
     P_SI = 1662, P_D6 = 1698, P_W = 1704, P_H12 = 1848, P_QV = 1860, P_CC = 1892, P_U12 = 1924,
     P_W12 = 1956, P_LAM6 = 1968, P_A = 1974,
     P_GCOL = 2004,    // friction-cone generators of ONE foot (16 x 6; both feet share vertices and rays)
@@ -145,6 +157,21 @@ enum {
     B_OB = S0 + 1382, // Om*beta (18) | 1/Om (18) | beta (18)
     B_LS = S0 + 1436, // 18 x 19 rows of L
     B_CF = S0 + 1778, // 18 x 18 full symmetric copy of Cm
+    // ---- phase B, NU = 15 (qp_setup15): every matrix-core operand is stored so that a lane's fragment is base + constant * k-step,
+    // zero-padded to the tile shape (rows beyond the matrix point at Q_ZERO), so the tiles run without bounds selects
+    Q_U = S0 + 0,      // 16 x 32 : U = [AG_lin ; J] rows, columns 30, 31 and row 15 zero
+    Q_UD = S0 + 512,   // 16 x 32 : U D^-1
+    Q_BPT = S0 + 1024, // 8 x 32  : rows 0..6 = columns of bp' = [-qref | D^-1 Mb'], row 7 = -qref + D^-1 U' Om beta (V's g column)
+    Q_TT = S0 + 1280,  // 8 x 16  : V' then t'' (row n = right-hand side n, k contiguous, [15] zero)
+    Q_CM = S0 + 1408,  // 16 x 16 : Cm, full
+    Q_Z = S0 + 1664,   // 6 x 16  : Mb D^-1 U'
+    Q_MBP = S0 + 1760, // 6 x 8   : Mb bp'
+    Q_S = S0 + 1808,   // 6 x 7
+    Q_T1 = S0 + 1856,  // 12 x 8 (columns 6, 7 zero)
+    Q_OB = S0 + 1952,  // Om*beta (16) | 1/Om (16) | beta (16)
+    Q_LS = S0 + 2000,  // 6 x 7 rows of L (S^-1)
+    Q_ZERO = S0 + 2048, // 32 zeros
+    Q_TRASH = S0 + 2080, // 64: where the lanes outside a tile's valid range store
     // ---- phase C (cone QP)
     C_WG = S0 + 0,    // 12 x 32
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
@@ -1398,11 +1425,69 @@ __device__ __forceinline__ void build_cone_matrix(double *L, const LmhDevParams 
     WSYNC();
 }
 
+// Row `ia` of the cone Hessian P = G'WG + eps I without forming it: P_ij = g_i' W_(f(i) f(j)) g_j, g_i = generator of coefficient i
+// (foot f(i) = i >> 4).  u_R = W_(f(i),R)' g_i and u_L = W_(f(i),L)' g_i (72 FMAs) serve every column of the row; column j then costs six
+// FMAs on operands read at a wave-uniform LDS address.  Replaces the six MFMA tiles + 32 x 33 LDS image of build_cone_matrix on the
+// general free-set route (|F| is usually <= 8 there: a foot pressing on an edge of its support polygon).
+struct ConeRow { double uR[6], uL[6]; };
+__device__ __forceinline__ ConeRow cone_row_prepare(const double *L, int ia)
+{
+    ConeRow q;
+    const double *gi = L + P_GCOL + 6 * (ia & 15), *Wr = L + P_W + 72 * (ia >> 4);
+    double g[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) g[a] = gi[a];
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        double sr = 0.0, sl = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) { sr += g[a] * Wr[12 * a + b]; sl += g[a] * Wr[12 * a + 6 + b]; }
+        q.uR[b] = sr; q.uL[b] = sl;
+    }
+    return q;
+}
+// The rows and columns of P that belong to the free set F (wave-uniform), written into the 32 x 33 image at C_P: lane r < |F| owns the r-th
+// free coefficient; the column loop is a scalar bit-scan over F (right-foot columns take u_R, left-foot columns u_L).
+__device__ __forceinline__ void build_cone_rows(double *L, unsigned F, double eps)
+{
+    const int lane = LANE;
+    int ia = 0;
+    {
+        unsigned m = F;
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            const int j = m ? __builtin_ctz(m) : 0;
+            m &= m - 1u;
+            ia = (lane == c) ? j : ia;
+        }
+    }
+    WSYNC();
+    const ConeRow q = cone_row_prepare(L, ia);
+    double *Pr = L + C_P + 33 * ia;                               // lanes beyond |F| recompute row 0 (same values)
+    for (unsigned m = F & 0xFFFFu; m; m &= m - 1u) {
+        const int j = __builtin_ctz(m);
+        const double *gj = L + P_GCOL + 6 * j;
+        double sacc = (ia == j) ? eps : 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) sacc += q.uR[b] * gj[b];
+        Pr[j] = sacc;
+    }
+    for (unsigned m = F >> 16; m; m &= m - 1u) {
+        const int j = __builtin_ctz(m);
+        const double *gj = L + P_GCOL + 6 * j;
+        double sacc = (ia == 16 + j) ? eps : 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) sacc += q.uL[b] * gj[b];
+        Pr[16 + j] = sacc;
+    }
+    WSYNC();
+}
+
 // Compacted solve for |F| <= N: lane r < nF owns the r-th free coefficient; the N x N register LDL' then only
 // visits live pivots.  F is wave-uniform, so the positions of its set bits come from a scalar bit-scan chain
 // (no LDS index table); z of coefficient j is read back from lane pos(j) with one lane permute.
 template <int N>
-__device__ __forceinline__ int solve_compact(double *L, unsigned F, int nF, int pos, double *zj_out)
+__device__ __forceinline__ int solve_compact(double *L, unsigned F, int nF, int pos, double eps, double *zj_out)
 {
     const int lane = LANE;
     double a[N], b[1];
@@ -1416,7 +1501,7 @@ __device__ __forceinline__ int solve_compact(double *L, unsigned F, int nF, int 
             ia = (lane == c) ? idx[c] : ia;
         }
         const bool on = lane < nF;
-        const double *Pr = L + C_P + 33 * ia;
+        const double *Pr = L + C_P + 33 * ia;                      // rows / columns of F only (build_cone_rows)
 #pragma unroll
         for (int c = 0; c < N; c++) a[c] = (on && c <= lane) ? Pr[idx[c]] : 0.0;
         b[0] = on ? L[P_QV + ia] : 0.0;
@@ -1428,7 +1513,7 @@ __device__ __forceinline__ int solve_compact(double *L, unsigned F, int nF, int 
 
 // |F| in 17..32: two rows per lane (ldl2_solve_regs); coefficient of compact row r < 16 in lane r (b0), of row
 // r >= 16 in lane r - 16 (b1).
-__device__ __forceinline__ int solve_compact2(double *L, unsigned F, int nF, int pos, double *zj_out)
+__device__ __forceinline__ int solve_compact2(double *L, unsigned F, int nF, int pos, double eps, double *zj_out)
 {
     const int lane = LANE;
     double a0[16], a1[32], b0, b1;
@@ -1458,7 +1543,7 @@ __device__ __forceinline__ int solve_compact2(double *L, unsigned F, int nF, int
 
 // Solve P_FF z_F = qv_F on the free set F (wave-uniform).  Returns z_j for lane j in F (0 otherwise) and, for
 // lanes j < 32 not in F, the multiplier lam_j = (P z - qv)_j.
-__device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_out, double *lam_out)
+__device__ __forceinline__ int solve_free_set(double *L, unsigned F, double eps, double *z_out, double *lam_out)
 {
     const int lane = LANE, r = lane & 31, half = lane >> 5;
     const bool inF = (lane < 32) && ((F >> lane) & 1u);
@@ -1466,14 +1551,15 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_o
     const int pos = __popc(F & ((1u << r) - 1u));
     int bad;
     double zr;
-    if (nF <= 8) bad = solve_compact<8>(L, F, nF, pos, &zr);
-    else if (nF <= 16) bad = solve_compact<16>(L, F, nF, pos, &zr);
-    else bad = solve_compact2(L, F, nF, pos, &zr);
+    if (nF <= 8) bad = solve_compact<8>(L, F, nF, pos, eps, &zr);
+    else if (nF <= 16) bad = solve_compact<16>(L, F, nF, pos, eps, &zr);
+    else bad = solve_compact2(L, F, nF, pos, eps, &zr);
     const double zj = inF ? zr : 0.0;
     WSYNC();
     if (lane < 32) L[P_CC + lane] = zj;
     WSYNC();
     double s = 0.0;
+#ifdef LMH_OLD_P
     {
         const double *Pr = L + C_P + 33 * r + 16 * half, *cc = L + P_CC + 16 * half;
 #pragma unroll
@@ -1484,6 +1570,31 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double *z_o
         const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(s), __double2hiint(s), false, false);
         s = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
     }
+#else
+    {   // (P z)_r = g_r' W (G z) + eps z_r through the wrench G z: three short LDS steps instead of a 32 x 32 image of P
+        (void)half;
+        double *wz = L + C_LS, *Wwz = L + C_LS + 16;               // the rows of L parked by the solve above are dead
+        if (lane < 12) {
+            const int ft = lane / 6, k = lane % 6;
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) sacc += L[P_GCOL + 6 * j + k] * L[P_CC + 16 * ft + j];
+            wz[lane] = sacc;
+        }
+        WSYNC();
+        if (lane < 12) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) sacc += L[P_W + 12 * lane + k] * wz[k];
+            Wwz[lane] = sacc;
+        }
+        WSYNC();
+        const double *g = L + P_GCOL + 6 * (r & 15), *y = Wwz + 6 * (r >> 4);
+        s = eps * zj;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += g[k] * y[k];
+    }
+#endif
     *z_out = zj;
     *lam_out = (lane < 32 && !((F >> lane) & 1u)) ? s - L[P_QV + r] : 0.0;
     return bad;
@@ -1764,8 +1875,12 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
             zj = fr ? sj : 0.0;
             lj = (lane < 32 && !fr) ? -P.eps_coeff * sj : 0.0;
         } else {
+#ifdef LMH_OLD_P
             if (!have_p) { build_cone_matrix(L, P); have_p = true; }
-            if (solve_free_set(L, F, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+#else
+            build_cone_rows(L, F, P.eps_coeff);                    // P_FF only (the multipliers go through the wrench G z)
+#endif
+            if (solve_free_set(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
         }
         if (dbgp && lane == 0 && it <= 12) { dbgp[4021 + 2 * it] = (double)clock64(); dbgp[4050 + it] = (double)__popc(F); }
         const bool inF = (lane < 32) && ((F >> lane) & 1u);
@@ -1818,6 +1933,224 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
     WSYNC();
     *F_io = F;
     *iters = it;
+    return flags;
+}
+
+// One 16 x 16 matrix-core tile from operands that are already laid out for it: lane l loads A[l & 15][4 kk + (l >> 4)] from a0[ASTEP kk]
+// and B[4 kk + (l >> 4)][l & 15] from b0[BSTEP kk]; all 2 KSTEPS loads are issued before the first v_mfma, no select in between.
+template <int KSTEPS, int ASTEP, int BSTEP>
+__device__ __forceinline__ v4d mfma_ptr(const double *a0, const double *b0)
+{
+    double av[KSTEPS], bv[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) { av[kk] = a0[ASTEP * kk]; bv[kk] = b0[BSTEP * kk]; }
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+    return acc;
+}
+
+// QP set-up for the reference's weights (angular-momentum weight 0: U = [AG_lin ; J] has 15 rows), controller.cpp:94-132 + the equality
+// blocks of :388-436, down to the cone problem data W, h, qv.  Same algebra as qp_setup<NU> below with two changes of association that
+// shorten the leading wave's path:
+//   * Cm ob - beta = U D^-1 U' ob, so the right-hand side fix-up becomes a column of bp' (q = D^-1 U' Om beta, formed beside the fills);
+//   * S | d = Mb Y = Mb bp' - (Mb D^-1 U') t'' : Z = Mb D^-1 U' and Mb bp' do not depend on the 15 x 15 solve and are formed by the helper
+//     wave while wave 0 solves; the Y tiles (needed only by the recovery) are formed by the helper wave while wave 0 goes on to S^-1, W, h.
+// NW = 2 joins: fills | Cm, q+V | solve, Z+Mbp | (S..qv), Y | -> the caller's join in front of the cone solve.
+template <int NW>
+__device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int wid, double *dbgp)
+{
+    const int lane = LANE;
+    int flags = 0;
+    constexpr int nU = 15;
+    const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
+    const int tr = lane & 15, tq = lane >> 4;                      // fragment row / k-quarter; result rows tq + 4 reg, column tr
+    // ---- fills: U, U D^-1 (padded 16 x 32), bp'' (8 x 32), weights
+    for (int e = lane + 64 * wid; e < 512; e += 64 * NW) {
+        const int r = e >> 5, c = e & 31;
+        const bool in = (r < nU) && (c < 30);
+        const int rs = in ? r : 0, cs = in ? c : 0;
+        const double va = L[P_AG + 30 * (3 + ((rs < 3) ? rs : 0)) + cs], vj = jdense(L, (rs >= 3) ? rs - 3 : 0, cs);
+        const double u = in ? ((rs < 3) ? va : vj) : 0.0;
+        const double iD = (c < 3) ? idp : (c < 6) ? ida : idj;
+        L[Q_U + e] = u;
+        L[Q_UD + e] = u * iD;
+    }
+    for (int e = lane + 64 * wid; e < 224; e += 64 * NW) {         // rows 0..6 of bp'' (row 7 follows the join)
+        const int n = e >> 5, i = e & 31;
+        const bool in = i < 30;
+        const int is = in ? i : 0;
+        const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
+        const double vq = -L[P_QREF + is], vm = L[P_MTOP + 30 * ((n > 0) ? n - 1 : 0) + is] * iDi;
+        L[Q_BPT + e] = in ? ((n == 0) ? vq : vm) : 0.0;
+    }
+    if (wid == NW - 1) {
+        if (lane < 16) {                                           // Om_r beta_r | 1 / Om_r | beta_r  (row 15: zeros)
+            const bool in = lane < nU;
+            const int rr = in ? 3 + lane : 3;                      // row of [AG ; J]
+            const double om = (rr < 6) ? P.w_com_lin : P.w_foot;
+            const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
+            L[Q_OB + lane] = in ? om * beta : 0.0;
+            L[Q_OB + 16 + lane] = in ? 1.0 / om : 1.0;
+            L[Q_OB + 32 + lane] = in ? beta : 0.0;
+        }
+        if (lane >= 32) L[Q_ZERO + lane - 32] = 0.0;
+        if (lane >= 16 && lane < 24) L[Q_TT + 16 * (lane - 16) + 15] = 0.0;     // k = 15 padding of the right-hand sides
+    }
+    WSTAMP(10);
+    bsync<NW>();
+    WSTAMP(11);
+    if (dbgp && LANE == 0) dbgp[4070] = (double)clock64();
+    const double *zero = L + Q_ZERO;
+    const double *u_row = L + Q_U + 32 * tr + tq;                  // A fragment of U (row tr < 16: row 15 is zero)
+    // ---- Cm = Om^-1 + U D^-1 U'  (wave 0)  |  q, then V = U [bp'_g + q | bp'_M]  (helper wave)
+    if (NW == 1 || wid == 1) {
+        if (lane < 32) {                                           // q_i = D^-1_i sum_r U[r][i] (Om beta)_r ; row 7 of bp'' = -qref + q
+            double q = 0.0;
+#pragma unroll
+            for (int r = 0; r < nU; r++) q += L[Q_U + 32 * r + lane] * L[Q_OB + r];
+            const double iDi = (lane < 3) ? idp : (lane < 6) ? ida : idj;
+            L[Q_BPT + 32 * 7 + lane] = L[Q_BPT + lane] + q * iDi;  // columns 30, 31: 0 + 0
+        }
+        WSYNC();
+        const double *b_row = (tr == 0) ? L + Q_BPT + 32 * 7 + tq : (tr < 7) ? L + Q_BPT + 32 * tr + tq : zero;
+        const v4d vv = mfma_ptr<8, 4, 4>(u_row, b_row);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {                              // V[r][n] -> TT[n][r], r = tq + 4 g < 16 (row 15 of U is zero: TT[n][15] = 0)
+            const int r = tq + 4 * g;
+            L[(tr < 8) ? Q_TT + 16 * tr + r : Q_TRASH + lane] = vv[g];
+        }
+    }
+    if (NW == 1 || wid == 0) {
+        const v4d cm = mfma_ptr<8, 4, 4>(u_row, L + Q_UD + 32 * tr + tq);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int r = tq + 4 * g;
+            L[Q_CM + 16 * r + tr] = cm[g] + ((r == tr) ? L[Q_OB + 16 + r] : 0.0);
+        }
+    }
+    WSTAMP(12);
+    bsync<NW>();
+    WSTAMP(13);
+    // ---- Cm t = V (7 right-hand sides): wave 0  |  Z = Mb D^-1 U', Mb bp': helper wave
+    if (NW == 1 || wid == 0) {
+        double a[nU], bb[7];
+        const int lr = (lane < 16) ? lane : 0;
+#pragma unroll
+        for (int c = 0; c < nU; c++) a[c] = L[Q_CM + 16 * lr + c];
+#pragma unroll
+        for (int r = 0; r < 7; r++) bb[r] = L[Q_TT + 16 * r + lr];
+        WSTAMP(14);
+        if (gj_solve_regs<nU, 7>(a, bb, (1u << nU) - 1u)) flags |= LMH_FLAG_NOT_SPD;
+        bb[0] -= L[Q_OB + lr];                                     // t'' = t_g - ob in column 0
+        if (lane < 16) {
+#pragma unroll
+            for (int r = 0; r < 7; r++) L[Q_TT + 16 * r + lane] = (lane < nU) ? bb[r] : 0.0;
+        }
+        WSTAMP(15);
+    }
+    if (NW == 1 || wid == 1) {
+        const double *m_row = (tr < 6) ? L + P_MTOP + 30 * tr + tq : zero;        // k = 30, 31 read the next row's first entries: finite, times the zero padding of B
+        const v4d zz = mfma_ptr<8, 4, 4>(m_row, (tr < nU) ? L + Q_UD + 32 * tr + tq : zero);
+        const v4d mb = mfma_ptr<8, 4, 4>(m_row, (tr < 7) ? L + Q_BPT + 32 * tr + tq : zero);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {                              // rows m = tq + 4 g < 6
+            const int m = tq + 4 * g;
+            L[(m < 6) ? Q_Z + 16 * m + tr : Q_TRASH + lane] = zz[g];
+            L[(m < 6 && tr < 8) ? Q_MBP + 8 * m + tr : Q_TRASH + lane] = mb[g];
+        }
+    }
+    bsync<NW>();
+    WSTAMP(16);
+    if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
+    const double *t_row = (tr < 7) ? L + Q_TT + 16 * tr + tq : zero;              // B fragment of t'' (column tr)
+    // ---- helper wave: Y = bp' - D^-1 U' t''  (30 x 7, stored transposed; only the recovery reads it)
+    if (NW == 1 || wid == 1) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const v4d yy = mfma_ptr<4, 128, 4>(L + Q_U + 32 * tq + 16 * mt + tr, t_row);        // A[m = i][k] = U[k][i]
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int i = 16 * mt + tq + 4 * g;
+                const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
+                const bool ok = (i < 30) && (tr < 7);
+                const double bpv = L[ok ? Q_BPT + 32 * tr + i : Q_ZERO];
+                L[ok ? P_YT + 30 * tr + i : Q_TRASH + lane] = bpv - yy[g] * iDi;
+            }
+        }
+        WSTAMP(17);
+    }
+    // ---- wave 0: S | d = Mb bp' - Z t''  ->  S^-1  ->  T1 = Jb S^-1  ->  [W | h]  ->  qv
+    if (NW == 1 || wid == 0) {
+        {
+            const v4d sy = mfma_ptr<4, 4, 4>((tr < 6) ? L + Q_Z + 16 * tr + tq : zero, t_row);
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int m = tq + 4 * g;
+                const bool ok = (m < 6) && (tr < 7);
+                const double val = L[ok ? Q_MBP + 8 * m + tr : Q_ZERO] - sy[g];
+                const double cv = L[P_C + ((m < 6) ? m : 0)];
+                L[!ok ? Q_TRASH + lane : (tr == 0) ? P_D6 + m : Q_S + 7 * m + (tr - 1)] = (tr == 0) ? cv - val : val;
+            }
+        }
+        WSYNC();
+        WSTAMP(19);
+        {   // Si = S^-1: six unit right-hand sides.  S is only moderately conditioned as far as LDL' is concerned, but Gauss-Jordan loses
+            // ~cond(S) more digits and leaves S^-1 (hence W) unsymmetric at the 1e-10 level, which the active-set tests of the cone QP
+            // (tolerances ~1e-14) do not survive: LDL' on the lower triangle here.
+            double a[6], bb[6];
+            const int lr = (lane < 6) ? lane : 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) { const double sv = L[Q_S + 7 * lr + c]; a[c] = (lane < 6 && c <= lane) ? sv : 0.0; bb[c] = (lane == c) ? 1.0 : 0.0; }
+            if (ldl_solve_regs<6, 6>(a, bb, 0x3Fu, L + Q_LS)) flags |= LMH_FLAG_NOT_SPD;
+#pragma unroll
+            for (int c = 0; c < 6; c++) L[(lane < 6) ? P_SI + 6 * lane + c : Q_TRASH + lane] = bb[c];
+        }
+        WSYNC();
+        WSTAMP(20);
+        {   // T1 = Jb Si (12 x 6), K = 6 in two k-steps: the lanes of k = 6, 7 (second step, tq >= 2) read zeros
+            const bool k2 = tq < 2;
+            const double *ja = (tr < 12) ? L + P_JC + 12 * tr + tq : zero, *sb = (tr < 6) ? L + P_SI + 6 * tq + tr : zero;   // B[k][n] = Si[k][n]
+            const double a0 = ja[0], b0 = sb[0], a1 = (k2 ? ja : zero)[k2 ? 4 : 0], b1 = (k2 ? sb : zero)[k2 ? 24 : 0];
+            v4d t1 = {0.0, 0.0, 0.0, 0.0};
+            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t1, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t1, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 3; g++) {                          // rows tq + 4 g < 12; columns 6, 7 come out as zeros (padding of the next tile)
+                const int m = tq + 4 * g;
+                L[(tr < 8) ? Q_T1 + 8 * m + tr : Q_TRASH + lane] = t1[g];
+            }
+        }
+        WSYNC();
+        WSTAMP(21);
+        {   // [W | h] = [w_force I + T1 Jb' | T1 d]
+            const bool k2 = tq < 2;
+            const double *ta = (tr < 12) ? L + Q_T1 + 8 * tr + tq : zero;
+            const double *jb = (tr < 12) ? L + P_JC + 12 * tr + tq : (tr == 12) ? L + P_D6 + tq : zero;
+            const double a0 = ta[0], a1 = ta[4];                   // T1 columns 6, 7 are zero
+            const double b0 = jb[0], b1 = (k2 ? jb : zero)[k2 ? 4 : 0];
+            v4d ww = {0.0, 0.0, 0.0, 0.0};
+            ww = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, ww, 0, 0, 0);
+            ww = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ww, 0, 0, 0);
+            const double wf = P.w_force;
+#pragma unroll
+            for (int g = 0; g < 3; g++) {
+                const int m = tq + 4 * g;
+                L[(tr < 12) ? P_W + 12 * m + tr : (tr == 12) ? P_H12 + m : Q_TRASH + lane] = ww[g] + ((m == tr) ? wf : 0.0);
+            }
+        }
+        WSTAMP(22);
+        if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
+        WSYNC();
+        if (lane < 32) {                                           // qv = G' h
+            const int o = 6 * (lane / 16);
+            double sacc = 0.0;
+            for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
+            L[P_QV + lane] = sacc;
+        }
+        WSYNC();
+        WSTAMP(23);
+    }
     return flags;
 }
 
@@ -1953,7 +2286,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int i = 16 * mt + tq + 4 * g;
-                if (i < 30 && tr < 7) L[P_Y + 7 * i + tr] = L[B_BP + 7 * i + tr] - yy[g] * ((i < 3) ? idp : (i < 6) ? ida : idj);
+                if (i < 30 && tr < 7) L[P_YT + 30 * tr + i] = L[B_BP + 7 * i + tr] - yy[g] * ((i < 3) ? idp : (i < 6) ? ida : idj);
             }
         }
     }
@@ -1965,7 +2298,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
     if (wid == 0) {                                                // a dependent chain of small products: wave 0
     {
         auto a_m = [=](int m, int k) { return ldz(L, m < 6 && k < 30, P_MTOP + 30 * m + k, P_MTOP); };
-        auto b_y = [=](int k, int n) { return ldz(L, n < 7 && k < 30, P_Y + 7 * k + n, P_Y); };
+        auto b_y = [=](int k, int n) { return ldz(L, n < 7 && k < 30, P_YT + 30 * n + k, P_YT); };
         const v4d sy = mfma_tile<8>(a_m, b_y);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -2036,7 +2369,9 @@ template <int NW>
 __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
 {
     const int lane = LANE;
-    int flags = (P.w_com_ang == 0.0) ? qp_setup<15, NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
+    int flags = (P.w_com_ang == 0.0) ? qp_setup15<NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
+    WSTAMP(18);
+    bsync<NW>();                                                   // Y (helper wave) is complete; the cone solve may overwrite the set-up scratch
     if (NW == 2 && wid != 0) { WSTAMP(26); bsync<NW>(); WSTAMP(27); return 0; }            // the active-set iteration and the recovery are sequential: wave 0;
                                                                    // the helper waits for the free set it will prepare K^-1 for
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
@@ -2074,8 +2409,8 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     if (lane < 6) L[P_LAM6 + lane] = lam;
     WSYNC();
     if (lane < 30) {
-        double s = L[P_Y + 7 * lane];
-        for (int k = 0; k < 6; k++) s += L[P_Y + 7 * lane + 1 + k] * L[P_LAM6 + k];
+        double s = L[P_YT + lane];
+        for (int k = 0; k < 6; k++) s += L[P_YT + 30 * (1 + k) + lane] * L[P_LAM6 + k];
         L[P_A + lane] = -s;
     }
     WSYNC();
@@ -2207,7 +2542,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         for (int e = lane; e < 12; e += 64) { dbg[1470 + e] = L[P_JPQP + e]; dbg[1679 + e] = L[P_FREF + e]; dbg[2081 + e] = L[P_H12 + e]; }
         for (int e = lane; e < 9; e += 64) dbg[1626 + e] = L[P_COM + e];
         for (int e = lane; e < 8; e += 64) dbg[1635 + e] = L[P_MPC + e];
-        for (int e = lane; e < 210; e += 64) dbg[1691 + e] = L[P_Y + e];
+        for (int e = lane; e < 210; e += 64) dbg[1691 + e] = L[P_YT + 30 * (e % 7) + e / 7];
         for (int e = lane; e < 36; e += 64) dbg[1901 + e] = L[P_SI + e];
         for (int e = lane; e < 1024; e += 64) dbg[2093 + e] = L[C_P + 33 * (e / 32) + e % 32];
         for (int e = lane; e < 32; e += 64) { dbg[3117 + e] = L[P_QV + e]; dbg[3149 + e] = L[P_CC + e]; }
@@ -2354,6 +2689,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, 
     int k = 0, iters = 0, flags = 0, itmax = 0;
     const double dt = P.dt;
 #ifdef LMH_SUBSTAMPS
+    if (lane == 0) g_bwait[wid] = 0;
     const long long t_launch = clock64();
 #endif
     // the leading wave carries the critical path: it wins issue arbitration against the helper wave of the robot it
@@ -2416,7 +2752,10 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, 
         WSYNC();
         store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
 #ifdef LMH_SUBSTAMPS
-        if (lane == 0) out[(size_t)LMH_OUT_STRIDE * inst + 78] = (double)(clock64() - t_launch);   // diagnostic build: this robot's cycles in the launch (pad slot)
+        if (lane == 0) {                                           // diagnostic build: this robot's cycles in the launch and inside barriers (pad slots)
+            out[(size_t)LMH_OUT_STRIDE * inst + 78] = (double)(clock64() - t_launch);
+            st[91] = (double)g_bwait[0]; st[92] = (double)g_bwait[1];
+        }
 #endif
         if (lane < 60) st[lane] = x;
         if (lane < 30) st[60 + lane] = L[P_VP + lane];
