@@ -169,8 +169,10 @@ def build_workload(args, ctl, first, count, total_ticks):
         return state, host
     sim_time = total_ticks * args.dt + 0.5
     n_steps = max(2, int((sim_time - args.settle_time) / args.step_time))
-    plan = trajectories.walk_plan(sim_time, args.dt, num_steps=n_steps, time_per_step=args.step_time, ds_time=args.ds_time, step_height=0.02,
-                                  settle_time=args.settle_time)
+    # the walking plan (ZMP samples, support phase, swing-foot polynomial segments) is generated ON THE DEVICE (lmh_gen_walk); it is read
+    # back only so that the CPU baseline leg replays exactly the same references
+    ctl.gen_walk(sim_time, num_steps=n_steps, time_per_step=args.step_time, ds_time=args.ds_time, step_height=0.02, settle_time=args.settle_time)
+    plan = ctl.get_refs()
     xs = step_lengths(first, count)
     raw = None
     if args.config == 4:
@@ -188,8 +190,6 @@ def build_workload(args, ctl, first, count, total_ticks):
         q0, zcom = ik_start_posture(dev)
         q0s, zc = np.tile(q0, (count, 1)), np.array([zcom])
         ctl.set_zcom(zc)
-    ctl.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
-    ctl.set_segments(plan["segs"], plan["seg_of_sample"])
     ctl.set_xscale(xs)
     state = ctl.new_state(q0s, np.zeros(30), t=0.0)
     host.update(q0=q0s, v=np.zeros((count, 30)), zcom=zc, zmp_x=plan["zmp_x"], zmp_y=plan["zmp_y"], phase=plan["phase"],

@@ -36,6 +36,7 @@ EXPORTS = [
     "lmh_eval", "lmh_eval_debug", "lmh_rollout", "lmh_ik", "lmh_eval_host", "lmh_set_prev_velocity_host",
     "lmh_synchronize", "lmh_robot_com", "lmh_robot_com_host", "lmh_last_out_host", "lmh_ik_host", "lmh_set_segments", "lmh_set_xscale",
     "lmh_make_summary", "lmh_write_summary", "lmh_read_summary", "lmh_write_log", "lmh_read_log",
+    "lmh_gen_walk", "lmh_gen_jump", "lmh_num_ref_samples", "lmh_num_segments", "lmh_get_refs",
 ]
 
 
@@ -94,6 +95,11 @@ def lib():
     L.lmh_set_segments.argtypes = [vp, vp, ip, vp, ip]
     L.lmh_set_xscale.argtypes = [vp, vp, ip]
     u64, u64p, dpp = C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+    L.lmh_gen_walk.argtypes = [vp, dp, ip, dp, dp, dp, dp, ip, dp]
+    L.lmh_gen_jump.argtypes = [vp, dp, dp, dp]
+    L.lmh_num_ref_samples.argtypes = [vp]
+    L.lmh_num_segments.argtypes = [vp]
+    L.lmh_get_refs.argtypes = [vp, vp, vp, vp, vp, vp]
     L.lmh_make_summary.argtypes = [vp, vp, vp, vp, vp, vp]
     L.lmh_write_summary.argtypes = [C.c_char_p, vp, u64, dp]
     L.lmh_read_summary.argtypes = [C.c_char_p, vp, u64, u64p, dpp]

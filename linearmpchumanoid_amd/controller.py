@@ -134,6 +134,26 @@ class BatchedController:
         so = np.ascontiguousarray(seg_of_sample, dtype=np.uint16)
         check(capi.lib().lmh_set_segments(self._h, _np_ptr(sg), sg.shape[0], _np_ptr(so), len(so)))
 
+    def gen_walk(self, simulation_time, num_steps=4, time_per_step=0.5, ds_time=0.1, step_height=0.02, settle_time=0.3,
+                 first_support=capi.PHASE_RIGHT, foot_y=0.05):
+        """lmh_gen_walk: the walking plan of trajectories.walk_plan generated by a device kernel (ZMP samples, support phase, swing
+        polynomial segments); nothing is uploaded."""
+        check(capi.lib().lmh_gen_walk(self._h, float(simulation_time), int(num_steps), float(time_per_step), float(ds_time), float(step_height),
+                                      float(settle_time), int(first_support), float(foot_y)))
+
+    def gen_jump(self, simulation_time, stance_time=0.4, flight_time=0.15):
+        """lmh_gen_jump: stance references with a flight phase (trajectories.jump_plan), generated on the device."""
+        check(capi.lib().lmh_gen_jump(self._h, float(simulation_time), float(stance_time), float(flight_time)))
+
+    def get_refs(self):
+        """The reference set the handle currently holds, read back from the device: dict(zmp_x, zmp_y, phase, segs, seg_of_sample)."""
+        n, ns = capi.lib().lmh_num_ref_samples(self._h), capi.lib().lmh_num_segments(self._h)
+        zx, zy = np.zeros(n), np.zeros(n)
+        ph = np.zeros(n, dtype=np.uint8)
+        segs = np.zeros((ns, capi.SEG_STRIDE)); sos = np.zeros(n, dtype=np.uint16)
+        check(capi.lib().lmh_get_refs(self._h, _np_ptr(zx), _np_ptr(zy), _np_ptr(ph), _np_ptr(segs) if ns else None, _np_ptr(sos) if ns else None))
+        return dict(zmp_x=zx, zmp_y=zy, phase=ph, segs=segs, seg_of_sample=sos)
+
     def set_xscale(self, xscale):
         """Per-instance step-length scale of ZMP x and x-axis foot polynomials ([B] or None)."""
         if xscale is None:

@@ -18,6 +18,8 @@ extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s);
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s);
 extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const LmhIkTarget *target, int32_t *iters, hipStream_t s);
+extern "C" void lmh_launch_gen_walk(const LmhWalkSpec *W, double *zx, double *zy, uint8_t *phase, double *segs, uint16_t *sos, hipStream_t s);
+extern "C" void lmh_launch_gen_jump(int n, double time_step, double stance_time, double flight_time, double *zx, double *zy, uint8_t *phase, hipStream_t s);
 extern "C" void lmh_launch_summary(int n, const double *state, const double *out, const int32_t *status, double *summary, hipStream_t s);
 
 static thread_local std::string g_err;
@@ -686,5 +688,82 @@ extern "C" int lmh_read_log(const char *path, double *log, uint64_t capacity, ui
     if (n_instances) *n_instances = hd.n_instances;
     if (dt) *dt = hd.dt;
     if (t0) *t0 = hd.t0;
+    return LMH_OK;
+}
+
+// ---------------------------------------------------------------------------- reference generators on the device
+static int alloc_refs(lmh_handle *h, int n, int n_seg)
+{
+    void **bufs[] = {(void **)&h->d_zx, (void **)&h->d_zy, (void **)&h->d_phase, (void **)&h->d_segs, (void **)&h->d_sos};
+    for (void **b : bufs) if (*b) { HIPCHK(hipFree(*b)); *b = nullptr; }
+    h->n_seg = 0; h->n_samples = 0;
+    HIPCHK(hipMalloc(&h->d_zx, sizeof(double) * (size_t)n));
+    HIPCHK(hipMalloc(&h->d_zy, sizeof(double) * (size_t)n));
+    HIPCHK(hipMalloc(&h->d_phase, (size_t)n));
+    if (n_seg > 0) {
+        HIPCHK(hipMalloc(&h->d_segs, sizeof(double) * LMH_SEG_STRIDE * (size_t)n_seg));
+        HIPCHK(hipMalloc(&h->d_sos, sizeof(uint16_t) * (size_t)n));
+    }
+    return LMH_OK;
+}
+
+extern "C" int lmh_gen_walk(lmh_handle *h, double simulation_time, int num_steps, double time_per_step, double ds_time, double step_height,
+                            double settle_time, int first_support, double foot_y)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    if (num_steps < 1 || num_steps > LMH_GEN_MAX_STEPS) return fail(LMH_ERR_BAD_ARG, "num_steps must be in [1, 126]");
+    if (!(time_per_step > 0.0) || !(ds_time >= 0.0) || !(ds_time < time_per_step) || !(settle_time >= 0.0) || !(simulation_time > 0.0))
+        return fail(LMH_ERR_BAD_ARG, "need 0 <= ds_time < time_per_step, settle_time >= 0, simulation_time > 0");
+    if (first_support != LMH_PHASE_RIGHT && first_support != LMH_PHASE_LEFT) return fail(LMH_ERR_BAD_ARG, "first_support must be LMH_PHASE_RIGHT or LMH_PHASE_LEFT");
+    const int n = (int)((simulation_time + 0.5) / h->cfg.dt);       // zmpGeneration.cpp:41
+    if (n < 1) return fail(LMH_ERR_BAD_ARG, "no samples");
+    HIPCHK(hipSetDevice(h->device));
+    const int n_seg = 2 * num_steps + 2;
+    int rc = alloc_refs(h, n, n_seg);
+    if (rc != LMH_OK) return rc;
+    LmhWalkSpec W;
+    W.time_step = h->cfg.dt; W.time_per_step = time_per_step; W.ds_time = ds_time; W.step_height = step_height; W.settle_time = settle_time; W.foot_y = foot_y;
+    W.n_samples = n; W.num_steps = num_steps; W.first_support = first_support; W.pad = 0;
+    lmh_launch_gen_walk(&W, h->d_zx, h->d_zy, h->d_phase, h->d_segs, h->d_sos, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    h->n_samples = n; h->n_seg = n_seg;
+    fill_params(h);
+    return LMH_OK;
+}
+
+extern "C" int lmh_gen_jump(lmh_handle *h, double simulation_time, double stance_time, double flight_time)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    if (!(stance_time >= 0.0) || !(flight_time >= 0.0) || !(simulation_time > 0.0)) return fail(LMH_ERR_BAD_ARG, "times must be non-negative");
+    const int n = (int)((simulation_time + 0.5) / h->cfg.dt);
+    if (n < 1) return fail(LMH_ERR_BAD_ARG, "no samples");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = alloc_refs(h, n, 0);
+    if (rc != LMH_OK) return rc;
+    lmh_launch_gen_jump(n, h->cfg.dt, stance_time, flight_time, h->d_zx, h->d_zy, h->d_phase, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    h->n_samples = n;
+    fill_params(h);
+    return LMH_OK;
+}
+
+extern "C" int lmh_num_ref_samples(const lmh_handle *h) { return h ? h->n_samples : 0; }
+extern "C" int lmh_num_segments(const lmh_handle *h) { return h ? h->n_seg : 0; }
+
+extern "C" int lmh_get_refs(lmh_handle *h, double *zx, double *zy, uint8_t *phase, double *segs, uint16_t *sos)
+{
+    if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n_samples;
+    if (zx) HIPCHK(hipMemcpy(zx, h->d_zx, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (zy) HIPCHK(hipMemcpy(zy, h->d_zy, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (phase) {
+        if (h->d_phase) HIPCHK(hipMemcpy(phase, h->d_phase, n, hipMemcpyDeviceToHost));
+        else std::memset(phase, 0, n);
+    }
+    if (segs && h->n_seg > 0) HIPCHK(hipMemcpy(segs, h->d_segs, sizeof(double) * LMH_SEG_STRIDE * (size_t)h->n_seg, hipMemcpyDeviceToHost));
+    if (sos && h->n_seg > 0) HIPCHK(hipMemcpy(sos, h->d_sos, sizeof(uint16_t) * n, hipMemcpyDeviceToHost));
     return LMH_OK;
 }

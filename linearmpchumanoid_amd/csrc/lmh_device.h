@@ -43,3 +43,10 @@ struct LmhDevParams {
     int32_t rFn[3];
     int32_t lFn[3];
 };
+
+// walking-plan generator (lmh_gen_walk): arguments of the device kernel
+#define LMH_GEN_MAX_STEPS 126
+struct LmhWalkSpec {
+    double time_step, time_per_step, ds_time, step_height, settle_time, foot_y;
+    int32_t n_samples, num_steps, first_support, pad;
+};

@@ -159,19 +159,20 @@ enum {
     B_CF = S0 + 1778, // 18 x 18 full symmetric copy of Cm
     // ---- phase B, NU = 15 (qp_setup15): every matrix-core operand is stored so that a lane's fragment is base + constant * k-step,
     // zero-padded to the tile shape (rows beyond the matrix point at Q_ZERO), so the tiles run without bounds selects
-    Q_U = S0 + 0,      // 16 x 32 : U = [AG_lin ; J] rows, columns 30, 31 and row 15 zero
-    Q_UD = S0 + 512,   // 16 x 32 : U D^-1
-    Q_BPT = S0 + 1024, // 8 x 32  : rows 0..6 = columns of bp' = [-qref | D^-1 Mb'], row 7 = -qref + D^-1 U' Om beta (V's g column)
-    Q_TT = S0 + 1280,  // 8 x 16  : V' then t'' (row n = right-hand side n, k contiguous, [15] zero)
-    Q_CM = S0 + 1408,  // 16 x 16 : Cm, full
-    Q_Z = S0 + 1664,   // 6 x 16  : Mb D^-1 U'
-    Q_MBP = S0 + 1760, // 6 x 8   : Mb bp'
-    Q_S = S0 + 1808,   // 6 x 7
-    Q_T1 = S0 + 1856,  // 12 x 8 (columns 6, 7 zero)
-    Q_OB = S0 + 1952,  // Om*beta (16) | 1/Om (16) | beta (16)
-    Q_LS = S0 + 2000,  // 6 x 7 rows of L (S^-1)
-    Q_ZERO = S0 + 2048, // 32 zeros
-    Q_TRASH = S0 + 2080, // 64: where the lanes outside a tile's valid range store
+    // row strides are padded (34, 18, 17, 10 doubles) so that the 16 rows a fragment load touches fall into different LDS banks
+    Q_U = S0 + 0,      // 16 x 34 : U = [AG_lin ; J] rows, columns 30, 31 and row 15 zero
+    Q_UD = S0 + 544,   // 16 x 34 : U D^-1
+    Q_BPT = S0 + 1088, // 8 x 34  : rows 0..6 = columns of bp' = [-qref | D^-1 Mb'], row 7 = -qref + D^-1 U' Om beta (V's g column)
+    Q_TT = S0 + 1360,  // 8 x 18  : V' then t'' (row n = right-hand side n, k contiguous, [15] zero)
+    Q_CM = S0 + 1504,  // 16 x 17 : Cm, full
+    Q_Z = S0 + 1776,   // 6 x 18  : Mb D^-1 U'
+    Q_MBP = S0 + 1884, // 6 x 8   : Mb bp'
+    Q_S = S0 + 1932,   // 6 x 7
+    Q_T1 = S0 + 1974,  // 12 x 10 (columns 6, 7 zero)
+    Q_OB = S0 + 2094,  // Om*beta (16) | 1/Om (16) | beta (16)
+    Q_LS = S0 + 2142,  // 6 x 7 scratch of the S^-1 step
+    Q_ZERO = S0 + 2184, // 32 zeros
+    Q_TRASH = S0 + 2216, // 64: where the lanes outside a tile's valid range store
     // ---- phase C (cone QP)
     C_WG = S0 + 0,    // 12 x 32
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
@@ -649,7 +650,30 @@ __device__ __forceinline__ v4d mfma_tile(FA a_of, FB b_of)
     return acc;
 }
 
-__device__ __forceinline__ void sincos_r(double x, double *s, double *c) { sincos(x, s, c); }
+// sin / cos of a joint angle (|x| of a few radians): Cody-Waite reduction by pi/2 in two pieces (exact for the |n| <= 2^20 that can occur)
+// and the fdlibm kernel polynomials on |r| <= pi/4 -- about 35 dependent-free fp64 operations, against several hundred instructions of
+// the library routine with its large-argument path.  Accurate to ~1 ulp (a host libm is ~0.5 ulp; the difference is 1e-16).
+__device__ __forceinline__ void sincos_r(double x, double *s, double *c)
+{
+#ifdef LMH_LIBM_SINCOS
+    sincos(x, s, c);
+#else
+    const double n = rint(x * 6.36619772367581382433e-01);        // 2 / pi
+    double r = fma(-n, 1.57079632673412561417e+00, x);             // pio2 to 33 bits: n * pio2_1 is exact
+    r = fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                              -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double sr = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cr = 1.0 - fma(0.5, z, -(z * z) * pc);
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+#endif
+}
 __device__ __forceinline__ void sincos_r(float x, float *s, float *c) { sincosf(x, s, c); }
 
 // ============================================================================ kinematics
@@ -1944,10 +1968,14 @@ __device__ __forceinline__ v4d mfma_ptr(const double *a0, const double *b0)
     double av[KSTEPS], bv[KSTEPS];
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; kk++) { av[kk] = a0[ASTEP * kk]; bv[kk] = b0[BSTEP * kk]; }
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    // two accumulation chains (even / odd k-steps): a dependent v_mfma_f64_16x16x4 pair is ~97 cycles apart, independent ones issue every ~33
+    v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
-    return acc;
+    for (int kk = 0; kk < KSTEPS; kk += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+        if (kk + 1 < KSTEPS) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk + 1], bv[kk + 1], acc2, 0, 0, 0);
+    }
+    return acc + acc2;
 }
 
 // QP set-up for the reference's weights (angular-momentum weight 0: U = [AG_lin ; J] has 15 rows), controller.cpp:94-132 + the equality
@@ -1967,14 +1995,14 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
     const int tr = lane & 15, tq = lane >> 4;                      // fragment row / k-quarter; result rows tq + 4 reg, column tr
     // ---- fills: U, U D^-1 (padded 16 x 32), bp'' (8 x 32), weights
     for (int e = lane + 64 * wid; e < 512; e += 64 * NW) {
-        const int r = e >> 5, c = e & 31;
+        const int r = e >> 5, c = e & 31, o = 34 * r + c;
         const bool in = (r < nU) && (c < 30);
         const int rs = in ? r : 0, cs = in ? c : 0;
         const double va = L[P_AG + 30 * (3 + ((rs < 3) ? rs : 0)) + cs], vj = jdense(L, (rs >= 3) ? rs - 3 : 0, cs);
         const double u = in ? ((rs < 3) ? va : vj) : 0.0;
         const double iD = (c < 3) ? idp : (c < 6) ? ida : idj;
-        L[Q_U + e] = u;
-        L[Q_UD + e] = u * iD;
+        L[Q_U + o] = u;
+        L[Q_UD + o] = u * iD;
     }
     for (int e = lane + 64 * wid; e < 224; e += 64 * NW) {         // rows 0..6 of bp'' (row 7 follows the join)
         const int n = e >> 5, i = e & 31;
@@ -1982,7 +2010,7 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
         const int is = in ? i : 0;
         const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
         const double vq = -L[P_QREF + is], vm = L[P_MTOP + 30 * ((n > 0) ? n - 1 : 0) + is] * iDi;
-        L[Q_BPT + e] = in ? ((n == 0) ? vq : vm) : 0.0;
+        L[Q_BPT + 34 * n + i] = in ? ((n == 0) ? vq : vm) : 0.0;
     }
     if (wid == NW - 1) {
         if (lane < 16) {                                           // Om_r beta_r | 1 / Om_r | beta_r  (row 15: zeros)
@@ -1995,38 +2023,38 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
             L[Q_OB + 32 + lane] = in ? beta : 0.0;
         }
         if (lane >= 32) L[Q_ZERO + lane - 32] = 0.0;
-        if (lane >= 16 && lane < 24) L[Q_TT + 16 * (lane - 16) + 15] = 0.0;     // k = 15 padding of the right-hand sides
+        if (lane >= 16 && lane < 24) L[Q_TT + 18 * (lane - 16) + 15] = 0.0;     // k = 15 padding of the right-hand sides
     }
     WSTAMP(10);
     bsync<NW>();
     WSTAMP(11);
     if (dbgp && LANE == 0) dbgp[4070] = (double)clock64();
     const double *zero = L + Q_ZERO;
-    const double *u_row = L + Q_U + 32 * tr + tq;                  // A fragment of U (row tr < 16: row 15 is zero)
+    const double *u_row = L + Q_U + 34 * tr + tq;                  // A fragment of U (row tr < 16: row 15 is zero)
     // ---- Cm = Om^-1 + U D^-1 U'  (wave 0)  |  q, then V = U [bp'_g + q | bp'_M]  (helper wave)
     if (NW == 1 || wid == 1) {
         if (lane < 32) {                                           // q_i = D^-1_i sum_r U[r][i] (Om beta)_r ; row 7 of bp'' = -qref + q
             double q = 0.0;
 #pragma unroll
-            for (int r = 0; r < nU; r++) q += L[Q_U + 32 * r + lane] * L[Q_OB + r];
+            for (int r = 0; r < nU; r++) q += L[Q_U + 34 * r + lane] * L[Q_OB + r];
             const double iDi = (lane < 3) ? idp : (lane < 6) ? ida : idj;
-            L[Q_BPT + 32 * 7 + lane] = L[Q_BPT + lane] + q * iDi;  // columns 30, 31: 0 + 0
+            L[Q_BPT + 34 * 7 + lane] = L[Q_BPT + lane] + q * iDi;  // columns 30, 31: 0 + 0
         }
         WSYNC();
-        const double *b_row = (tr == 0) ? L + Q_BPT + 32 * 7 + tq : (tr < 7) ? L + Q_BPT + 32 * tr + tq : zero;
+        const double *b_row = (tr == 0) ? L + Q_BPT + 34 * 7 + tq : (tr < 7) ? L + Q_BPT + 34 * tr + tq : zero;
         const v4d vv = mfma_ptr<8, 4, 4>(u_row, b_row);
 #pragma unroll
         for (int g = 0; g < 4; g++) {                              // V[r][n] -> TT[n][r], r = tq + 4 g < 16 (row 15 of U is zero: TT[n][15] = 0)
             const int r = tq + 4 * g;
-            L[(tr < 8) ? Q_TT + 16 * tr + r : Q_TRASH + lane] = vv[g];
+            L[(tr < 8) ? Q_TT + 18 * tr + r : Q_TRASH + lane] = vv[g];
         }
     }
     if (NW == 1 || wid == 0) {
-        const v4d cm = mfma_ptr<8, 4, 4>(u_row, L + Q_UD + 32 * tr + tq);
+        const v4d cm = mfma_ptr<8, 4, 4>(u_row, L + Q_UD + 34 * tr + tq);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int r = tq + 4 * g;
-            L[Q_CM + 16 * r + tr] = cm[g] + ((r == tr) ? L[Q_OB + 16 + r] : 0.0);
+            L[Q_CM + 17 * r + tr] = cm[g] + ((r == tr) ? L[Q_OB + 16 + r] : 0.0);
         }
     }
     WSTAMP(12);
@@ -2037,44 +2065,44 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
         double a[nU], bb[7];
         const int lr = (lane < 16) ? lane : 0;
 #pragma unroll
-        for (int c = 0; c < nU; c++) a[c] = L[Q_CM + 16 * lr + c];
+        for (int c = 0; c < nU; c++) a[c] = L[Q_CM + 17 * lr + c];
 #pragma unroll
-        for (int r = 0; r < 7; r++) bb[r] = L[Q_TT + 16 * r + lr];
+        for (int r = 0; r < 7; r++) bb[r] = L[Q_TT + 18 * r + lr];
         WSTAMP(14);
         if (gj_solve_regs<nU, 7>(a, bb, (1u << nU) - 1u)) flags |= LMH_FLAG_NOT_SPD;
         bb[0] -= L[Q_OB + lr];                                     // t'' = t_g - ob in column 0
         if (lane < 16) {
 #pragma unroll
-            for (int r = 0; r < 7; r++) L[Q_TT + 16 * r + lane] = (lane < nU) ? bb[r] : 0.0;
+            for (int r = 0; r < 7; r++) L[Q_TT + 18 * r + lane] = (lane < nU) ? bb[r] : 0.0;
         }
         WSTAMP(15);
     }
     if (NW == 1 || wid == 1) {
         const double *m_row = (tr < 6) ? L + P_MTOP + 30 * tr + tq : zero;        // k = 30, 31 read the next row's first entries: finite, times the zero padding of B
-        const v4d zz = mfma_ptr<8, 4, 4>(m_row, (tr < nU) ? L + Q_UD + 32 * tr + tq : zero);
-        const v4d mb = mfma_ptr<8, 4, 4>(m_row, (tr < 7) ? L + Q_BPT + 32 * tr + tq : zero);
+        const v4d zz = mfma_ptr<8, 4, 4>(m_row, (tr < nU) ? L + Q_UD + 34 * tr + tq : zero);
+        const v4d mb = mfma_ptr<8, 4, 4>(m_row, (tr < 7) ? L + Q_BPT + 34 * tr + tq : zero);
 #pragma unroll
         for (int g = 0; g < 2; g++) {                              // rows m = tq + 4 g < 6
             const int m = tq + 4 * g;
-            L[(m < 6) ? Q_Z + 16 * m + tr : Q_TRASH + lane] = zz[g];
+            L[(m < 6) ? Q_Z + 18 * m + tr : Q_TRASH + lane] = zz[g];
             L[(m < 6 && tr < 8) ? Q_MBP + 8 * m + tr : Q_TRASH + lane] = mb[g];
         }
     }
     bsync<NW>();
     WSTAMP(16);
     if (dbgp && LANE == 0) dbgp[4074] = (double)clock64();
-    const double *t_row = (tr < 7) ? L + Q_TT + 16 * tr + tq : zero;              // B fragment of t'' (column tr)
+    const double *t_row = (tr < 7) ? L + Q_TT + 18 * tr + tq : zero;              // B fragment of t'' (column tr)
     // ---- helper wave: Y = bp' - D^-1 U' t''  (30 x 7, stored transposed; only the recovery reads it)
     if (NW == 1 || wid == 1) {
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
-            const v4d yy = mfma_ptr<4, 128, 4>(L + Q_U + 32 * tq + 16 * mt + tr, t_row);        // A[m = i][k] = U[k][i]
+            const v4d yy = mfma_ptr<4, 136, 4>(L + Q_U + 34 * tq + 16 * mt + tr, t_row);        // A[m = i][k] = U[k][i]
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int i = 16 * mt + tq + 4 * g;
                 const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
                 const bool ok = (i < 30) && (tr < 7);
-                const double bpv = L[ok ? Q_BPT + 32 * tr + i : Q_ZERO];
+                const double bpv = L[ok ? Q_BPT + 34 * tr + i : Q_ZERO];
                 L[ok ? P_YT + 30 * tr + i : Q_TRASH + lane] = bpv - yy[g] * iDi;
             }
         }
@@ -2083,7 +2111,7 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
     // ---- wave 0: S | d = Mb bp' - Z t''  ->  S^-1  ->  T1 = Jb S^-1  ->  [W | h]  ->  qv
     if (NW == 1 || wid == 0) {
         {
-            const v4d sy = mfma_ptr<4, 4, 4>((tr < 6) ? L + Q_Z + 16 * tr + tq : zero, t_row);
+            const v4d sy = mfma_ptr<4, 4, 4>((tr < 6) ? L + Q_Z + 18 * tr + tq : zero, t_row);
 #pragma unroll
             for (int g = 0; g < 2; g++) {
                 const int m = tq + 4 * g;
@@ -2100,11 +2128,28 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
             // (tolerances ~1e-14) do not survive: LDL' on the lower triangle here.
             double a[6], bb[6];
             const int lr = (lane < 6) ? lane : 0;
+#ifndef LMH_LDL_SI
+            // Gauss-Jordan on the full S, then S^-1 <- (S^-1 + S^-T) / 2: plain Gauss-Jordan leaves S^-1 (hence W) unsymmetric at the 1e-10 level (it loses
+            // ~cond(S) more digits than LDL'), which the active-set tests of the cone QP (tolerances ~1e-14) do not survive; symmetrised, W is symmetric to
+            // round-off again and the solve is 1.5k cycles shorter than LDL' with its parked factor (LMH_LDL_SI keeps that form for comparison)
+#pragma unroll
+            for (int c = 0; c < 6; c++) { a[c] = L[Q_S + 7 * lr + c]; bb[c] = (lane == c) ? 1.0 : 0.0; }
+            if (gj_solve_regs<6, 6>(a, bb, 0x3Fu)) flags |= LMH_FLAG_NOT_SPD;
+#pragma unroll
+            for (int c = 0; c < 6; c++) L[(lane < 6) ? Q_LS + 6 * lane + c : Q_TRASH + lane] = bb[c];
+            WSYNC();
+            {
+                const int e = (lane < 36) ? lane : 0, i = e / 6, j = e % 6;
+                const double v = 0.5 * (L[Q_LS + 6 * i + j] + L[Q_LS + 6 * j + i]);
+                L[(lane < 36) ? P_SI + e : Q_TRASH + lane] = v;
+            }
+#else
 #pragma unroll
             for (int c = 0; c < 6; c++) { const double sv = L[Q_S + 7 * lr + c]; a[c] = (lane < 6 && c <= lane) ? sv : 0.0; bb[c] = (lane == c) ? 1.0 : 0.0; }
             if (ldl_solve_regs<6, 6>(a, bb, 0x3Fu, L + Q_LS)) flags |= LMH_FLAG_NOT_SPD;
 #pragma unroll
             for (int c = 0; c < 6; c++) L[(lane < 6) ? P_SI + 6 * lane + c : Q_TRASH + lane] = bb[c];
+#endif
         }
         WSYNC();
         WSTAMP(20);
@@ -2118,14 +2163,14 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
 #pragma unroll
             for (int g = 0; g < 3; g++) {                          // rows tq + 4 g < 12; columns 6, 7 come out as zeros (padding of the next tile)
                 const int m = tq + 4 * g;
-                L[(tr < 8) ? Q_T1 + 8 * m + tr : Q_TRASH + lane] = t1[g];
+                L[(tr < 8) ? Q_T1 + 10 * m + tr : Q_TRASH + lane] = t1[g];
             }
         }
         WSYNC();
         WSTAMP(21);
         {   // [W | h] = [w_force I + T1 Jb' | T1 d]
             const bool k2 = tq < 2;
-            const double *ta = (tr < 12) ? L + Q_T1 + 8 * tr + tq : zero;
+            const double *ta = (tr < 12) ? L + Q_T1 + 10 * tr + tq : zero;
             const double *jb = (tr < 12) ? L + P_JC + 12 * tr + tq : (tr == 12) ? L + P_D6 + tq : zero;
             const double a0 = ta[0], a1 = ta[4];                   // T1 columns 6, 7 are zero
             const double b0 = jb[0], b1 = (k2 ? jb : zero)[k2 ? 4 : 0];
@@ -3048,6 +3093,105 @@ __global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P, const doubl
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s)
 {
     hipLaunchKernelGGL(lmh_com_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, com);
+}
+
+// ============================================================================ reference generators on the device
+// The reference declares a walking generator (ZMP(Task, numSteps, timePerStep, simulationTime) / walkZMP, zmpGeneration.hpp:15-22) but never
+// defines it, and produces one polynomial set per step with footCoeffTrajectory / findPolyCoeff (footRefTrajectory.cpp:4-47,
+// generalizedFunctions.cpp:103-163).  The build's definition (the same one linearmpchumanoid_amd/trajectories.walk_plan states on the host):
+//   settle in double support, then num_steps steps of [double support ds_time | single support time_per_step - ds_time]; the ZMP sits at the
+//   mid-point of the feet in double support and under the support foot (y = -/+ foot_y) in single support; the swing foot follows the
+//   footCoeffTrajectory polynomials (5th order x / y, 7th order z through step_height at half time); x is in units of the step length
+//   (first and last step one unit, the others two), the per-instance scale (lmh_set_xscale) turns it into metres.
+// The swing polynomials are written in closed form instead of solving findPolyCoeff's Vandermonde system: with s = t / T,
+//   x, y : p0 + (p1 - p0)(10 s^3 - 15 s^4 + 6 s^5)
+//   z    : z0 P0(s) + h 64 r(s) + z1 P0(1 - s),   r = s^3 (1 - s)^3,   P0 = 1 - (10 s^3 - 15 s^4 + 6 s^5) - 32 r + 120 (s - 1/2) r
+// which is THE polynomial of degree <= 7 through the eight conditions of footRefTrajectory.cpp:20-44 (agrees with the solved system to 2e-13).
+__device__ __forceinline__ int gen_idx(double t, double time_step, int n)      // min(n, max(0, int(round(t / time_step)))), round half to even
+{
+    const double r = rint(t / time_step);
+    const int i = (r < 0.0) ? 0 : (r > (double)n ? n : (int)r);
+    return i;
+}
+__global__ void __launch_bounds__(256) lmh_gen_walk_kernel(LmhWalkSpec W, double *zx, double *zy, uint8_t *phase, double *segs, uint16_t *sos)
+{
+    __shared__ int s_a[LMH_GEN_MAX_STEPS + 1], s_b[LMH_GEN_MAX_STEPS], s_c[LMH_GEN_MAX_STEPS], s_sup[LMH_GEN_MAX_STEPS];
+    __shared__ double s_xr[LMH_GEN_MAX_STEPS + 1], s_xl[LMH_GEN_MAX_STEPS + 1], s_t[LMH_GEN_MAX_STEPS + 1];
+    const int n = W.n_samples, ns = W.num_steps, tid = threadIdx.x;
+    if (tid == 0) {                                                // the step boundaries accumulate t += time_per_step in order: one thread
+        double t = W.settle_time, xr = 0.0, xl = 0.0;
+        int sup = W.first_support;
+        for (int s = 0; s < ns; s++) {
+            const double stride = (s == 0 || s == ns - 1) ? 1.0 : 2.0;
+            s_a[s] = gen_idx(t, W.time_step, n); s_b[s] = gen_idx(t + W.ds_time, W.time_step, n); s_c[s] = gen_idx(t + W.time_per_step, W.time_step, n);
+            s_xr[s] = xr; s_xl[s] = xl; s_t[s] = t; s_sup[s] = sup;
+            if (sup == LMH_PHASE_RIGHT) xl += stride; else xr += stride;
+            sup = (sup == LMH_PHASE_RIGHT) ? LMH_PHASE_LEFT : LMH_PHASE_RIGHT;
+            t += W.time_per_step;
+        }
+        s_a[ns] = gen_idx(t, W.time_step, n); s_xr[ns] = xr; s_xl[ns] = xl; s_t[ns] = t;
+    }
+    __syncthreads();
+    // ---- segment records: 0 = initial stance, 1 + 2 s = double support of step s, 2 + 2 s = its single support, 2 ns + 1 = final stance
+    const int n_seg = 2 * ns + 2;
+    for (int e = tid; e < n_seg * LMH_SEG_STRIDE; e += blockDim.x) {
+        const int g = e / LMH_SEG_STRIDE, f = e % LMH_SEG_STRIDE;
+        const bool first = g == 0, last = g == n_seg - 1;
+        const int s = first ? 0 : last ? ns : (g - 1) >> 1;
+        const bool swing = !first && !last && ((g - 1) & 1);
+        const double xr = s_xr[s], xl = s_xl[s];
+        double v = 0.0;
+        if (f == 0) v = first ? 0.0 : swing ? (double)s_b[s] * W.time_step : s_t[s];
+        else if (f <= 48) {
+            const int ft = (f - 1) / 24, ax = ((f - 1) % 24) / 8, k = (f - 1) % 8;
+            const double x0 = ft ? xl : xr, y0 = ft ? W.foot_y : -W.foot_y;
+            const bool moving = swing && ((s_sup[s] == LMH_PHASE_RIGHT) == (ft == 1));    // right foot supports <-> the left foot swings
+            if (!moving) v = (k == 0) ? ((ax == 0) ? x0 : (ax == 1) ? y0 : 0.0) : 0.0;
+            else {
+                const double T = (double)(s_c[s] - s_b[s]) * W.time_step;
+                const double stride = (s == 0 || s == ns - 1) ? 1.0 : 2.0;
+                double chat;                                       // coefficient of s^k, s = t / T
+                if (ax == 0) { const double d = (x0 + stride) - x0; chat = (k == 0) ? x0 : (k == 3) ? 10.0 * d : (k == 4) ? -15.0 * d : (k == 5) ? 6.0 * d : 0.0; }
+                else if (ax == 1) chat = (k == 0) ? y0 : 0.0;      // the swing foot keeps its y
+                else chat = W.step_height * ((k == 3) ? 64.0 : (k == 4) ? -192.0 : (k == 5) ? 192.0 : (k == 6) ? -64.0 : 0.0);   // z0 = z1 = 0
+                double tp = 1.0;
+                for (int i = 0; i < k; i++) tp *= T;
+                v = chat / tp;
+            }
+        }
+        segs[e] = v;
+    }
+    // ---- samples: the assignments of the host generator in their order (the last one that covers k wins)
+    for (int k = tid; k < n; k += blockDim.x) {
+        double x = 0.0, y = 0.0;
+        int ph = LMH_PHASE_DOUBLE, sg = 0;
+        for (int s = 0; s < ns; s++) {
+            if (k >= s_a[s] && k < s_b[s]) { x = 0.5 * (s_xr[s] + s_xl[s]); y = 0.0; ph = LMH_PHASE_DOUBLE; sg = 1 + 2 * s; }
+            if (k >= s_b[s] && k < s_c[s]) {
+                const bool right = s_sup[s] == LMH_PHASE_RIGHT;
+                x = right ? s_xr[s] : s_xl[s]; y = right ? -W.foot_y : W.foot_y; ph = s_sup[s]; sg = 2 + 2 * s;
+            }
+        }
+        if (k >= s_a[ns]) { x = 0.5 * (s_xr[ns] + s_xl[ns]); y = 0.0; ph = LMH_PHASE_DOUBLE; sg = 2 * ns + 1; }
+        zx[k] = x; zy[k] = y; phase[k] = (uint8_t)ph; sos[k] = (uint16_t)sg;
+    }
+}
+// jumping schedule (BASELINE config 5): stance ZMP references (ZMP::stanceZMP, Double), PHASE_FLIGHT in [stance, stance + flight)
+__global__ void __launch_bounds__(256) lmh_gen_jump_kernel(int n, double time_step, double stance_time, double flight_time, double *zx, double *zy, uint8_t *phase)
+{
+    const int a = gen_idx(stance_time, time_step, n), b = gen_idx(stance_time + flight_time, time_step, n);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        zx[k] = 0.0; zy[k] = 0.0;
+        phase[k] = (uint8_t)((k >= a && k < b) ? LMH_PHASE_FLIGHT : LMH_PHASE_DOUBLE);
+    }
+}
+extern "C" void lmh_launch_gen_walk(const LmhWalkSpec *W, double *zx, double *zy, uint8_t *phase, double *segs, uint16_t *sos, hipStream_t s)
+{
+    hipLaunchKernelGGL(lmh_gen_walk_kernel, dim3(1), dim3(256), 0, s, *W, zx, zy, phase, segs, sos);
+}
+extern "C" void lmh_launch_gen_jump(int n, double time_step, double stance_time, double flight_time, double *zx, double *zy, uint8_t *phase, hipStream_t s)
+{
+    hipLaunchKernelGGL(lmh_gen_jump_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, time_step, stance_time, flight_time, zx, zy, phase);
 }
 
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s)

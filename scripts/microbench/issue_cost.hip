@@ -14,7 +14,7 @@ __global__ void k(long long *out, double *sink)
     double a0 = lane * 0.5, a1 = 1.0 + lane, a2 = 2.0, a3 = 3.0, a4 = 4, a5 = 5, a6 = 6, a7 = 7, m = 1.0000001, s = lane * 0.25 + 1.0;
     L[lane] = a0; L[lane + 64] = a1;
     __syncthreads();
-    long long t[16];
+    long long t[20];
     int ti = 0;
     // 0: empty
     t[ti++] = now(); t[ti++] = now();
@@ -59,20 +59,35 @@ __global__ void k(long long *out, double *sink)
     t[ti] = now();
     asm volatile(REP8("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 %1, 0x1f8, %1\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 %1, 0x1f8, %1\n\t") : "+v"(a7), "+v"(addr));
     t[++ti] = now(); ti++;
-    if (lane == 0) for (int i = 0; i < 16; i++) out[i] = t[i];
+    // 8: 16 dependent v_mfma_f64_16x16x4_f64 (one accumulator)
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    v4d acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    t[ti] = now();
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, s, acc, 0, 0, 0);
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
+    t[++ti] = now(); ti++;
+    // 9: 16 v_mfma_f64_16x16x4_f64 on two alternating accumulators
+    t[ti] = now();
+#pragma unroll
+    for (int i = 0; i < 8; i++) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, s, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, s, acc2, 0, 0, 0); }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc), "+v"(acc2));
+    t[++ti] = now(); ti++;
+    a0 += acc[0] + acc[1] + acc2[2] + acc2[3];
+    if (lane == 0) for (int i = 0; i < 20; i++) out[i] = t[i];
     sink[lane] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + s + addr;
 }
 
 int main()
 {
     long long *d; double *sink;
-    hipMalloc(&d, 16 * 8); hipMalloc(&sink, 64 * 8);
+    hipMalloc(&d, 20 * 8); hipMalloc(&sink, 64 * 8);
     for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d, sink);
-    std::vector<long long> h(16);
-    hipMemcpy(h.data(), d, 16 * 8, hipMemcpyDeviceToHost);
-    const char *nm[] = {"empty", "64 indep v_fma_f64", "64 dep v_fma_f64", "64 indep v_fmac_f64_dpp row_newbcast", "64 x (2 readlane + fma sgpr)", "64 v_mov_b64_dpp", "16 dep v_rcp_f64", "16 dep ds_read_b64"};
-    const int cnt[] = {1, 64, 64, 64, 64, 64, 16, 16};
+    std::vector<long long> h(20);
+    hipMemcpy(h.data(), d, 20 * 8, hipMemcpyDeviceToHost);
+    const char *nm[] = {"empty", "64 indep v_fma_f64", "64 dep v_fma_f64", "64 indep v_fmac_f64_dpp row_newbcast", "64 x (2 readlane + fma sgpr)", "64 v_mov_b64_dpp", "16 dep v_rcp_f64", "16 dep ds_read_b64", "16 dep v_mfma_f64_16x16x4 (+32 nop)", "16 v_mfma_f64_16x16x4, 2 accumulators (+32 nop)"};
+    const int cnt[] = {1, 64, 64, 64, 64, 64, 16, 16, 16, 16};
     const long long base = h[1] - h[0];
-    for (int i = 0; i < 8; i++) printf("%-40s total %6lld  -> %.1f cycles each\n", nm[i], h[2 * i + 1] - h[2 * i], (double)(h[2 * i + 1] - h[2 * i] - base) / cnt[i]);
+    for (int i = 0; i < 10; i++) printf("%-40s total %6lld  -> %.1f cycles each\n", nm[i], h[2 * i + 1] - h[2 * i], (double)(h[2 * i + 1] - h[2 * i] - base) / cnt[i]);
     return 0;
 }

@@ -1,16 +1,18 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + PMC passes of the default bench workload.
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + PMC passes of a bench workload.
 # Counters are collected in their own passes (never combined with a trace domain).  Output: gpurun_out/prof_$1/
-# then summarised by scripts/summarise_profile.py into profiles/.
+# then summarised by scripts/summarise_profile.py into profiles/.   Usage: profile_rollout.sh TAG [bench.py args, e.g. --config 2]
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02_c3}
+shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
+rm -rf $O
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $R/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B --steps 20 --warmup 3 > $O/kt.log 2>&1
+B="python3 $R/bench.py --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- $B --steps 5 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- $B --steps 5 --warmup 1 > $O/write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS \

@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/prof_<tag>/ (scripts/profile_rollout.sh) into profiles/<tag>_kernel_stats.csv and
-profiles/<tag>_rollout_summary.json.  Usage: python scripts/summarise_profile.py r01b [instances ticks]"""
+profiles/<tag>_rollout_summary.json.  Usage: python scripts/summarise_profile.py r02_c3 [instances ticks]
+(defaults: the workload of the bench line found in the profile directory)"""
 import csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
+_bl = os.path.join(src, "bench_line.json")
+_cfg = json.loads(open(_bl).read().strip().splitlines()[-1])["config"] if os.path.exists(_bl) and os.path.getsize(_bl) else {}
+B = int(sys.argv[2]) if len(sys.argv) > 2 else int(_cfg.get("instances_per_gpu", 1024))
+ticks = int(sys.argv[3]) if len(sys.argv) > 3 else int(_cfg.get("ticks_per_step", 10))
 KERNEL = "lmh_rollout_kernel"
 
 
@@ -58,7 +61,7 @@ derived = {
             "access width here is 8 B/lane (uncalibrated), so the read side is bracketed by [raw, 2x raw]",
 }
 out = {
-    "command": "scripts/profile_rollout.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline; PMC: separate --pmc passes, --steps 5 --warmup 1",
+    "command": "scripts/profile_rollout.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline [config args] (the default bench command); PMC: separate --pmc passes, --steps 5 --warmup 1",
     "kernel": KERNEL, "dispatch": meta, "workload": f"{B} instances x {ticks} RK4 ticks per launch",
     "avg_launch_ns": avg_ns, "calls": calls, "pmc_per_launch": pmc, "derived": derived,
 }

@@ -338,6 +338,75 @@ def test_config5_jump_schedule_full_size():
     assert checked == 8
 
 
+# ------------------------------------------------------------------------------- device-side reference generators
+@pytest.mark.parametrize("gait", [
+    dict(simulation_time=2.5, num_steps=4, time_per_step=0.5, ds_time=0.1, step_height=0.02, settle_time=0.3, first_support=1, foot_y=0.05),
+    dict(simulation_time=1.0, num_steps=2, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.1, first_support=1, foot_y=0.05),
+    dict(simulation_time=1.3, num_steps=7, time_per_step=0.17, ds_time=0.033, step_height=0.015, settle_time=0.0731, first_support=2, foot_y=0.045),
+    dict(simulation_time=0.35, num_steps=5, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.1, first_support=1, foot_y=0.05),  # plan ends beyond the sample grid
+])
+def test_walk_generator_kernel_matches_the_host_plan(gait):
+    """lmh_gen_walk (device kernel) against trajectories.walk_plan (host statement of the same plan): ZMP samples, support phase and
+    seg_of_sample BIT-exact, segment start times exact, stance coefficients exact, swing polynomials (closed form on the device,
+    findPolyCoeff's linear solve on the host) equal in position / velocity / acceleration to 1e-12 over the swing."""
+    from linearmpchumanoid_amd import trajectories
+    dt = 1e-3
+    ctl = make_controller(2, dt, 0.032, 0.26)
+    ctl.gen_walk(**gait)
+    g = ctl.get_refs()
+    p = trajectories.walk_plan(gait["simulation_time"], dt, **{k: v for k, v in gait.items() if k != "simulation_time"})
+    assert np.array_equal(g["phase"], p["phase"]) and np.array_equal(g["seg_of_sample"], p["seg_of_sample"])
+    assert np.array_equal(g["zmp_x"], p["zmp_x"]) and np.array_equal(g["zmp_y"], p["zmp_y"])
+    assert g["segs"].shape == p["segs"].shape
+    assert np.array_equal(g["segs"][:, 0], p["segs"][:, 0])
+    for sgd, sgh in zip(g["segs"], p["segs"]):
+        T = max(gait["time_per_step"] - gait["ds_time"], dt)
+        t = np.linspace(0.0, T, 41)
+        for ft in range(2):
+            for ax in range(3):
+                cd, ch = sgd[1 + 24 * ft + 8 * ax: 9 + 24 * ft + 8 * ax], sgh[1 + 24 * ft + 8 * ax: 9 + 24 * ft + 8 * ax]
+                if not np.abs(ch[1:]).max() > 1e-9:                # a standing foot: constants, exactly
+                    assert cd[0] == ch[0] and np.abs(cd[1:]).max() == 0.0
+                    continue
+                for der in range(3):
+                    pd = np.polynomial.polynomial.Polynomial(cd).deriv(der)(t) if der else np.polynomial.polynomial.polyval(t, cd)
+                    phh = np.polynomial.polynomial.Polynomial(ch).deriv(der)(t) if der else np.polynomial.polynomial.polyval(t, ch)
+                    assert np.abs(pd - phh).max() < 1e-12 * max(1.0, np.abs(phh).max()), (ft, ax, der)
+                assert np.abs(cd - ch).max() < 1e-11 * np.abs(ch).max()
+
+
+def test_jump_generator_kernel_and_rollout_on_generated_plans(cfg2):
+    """lmh_gen_jump against trajectories.jump_plan (exact), and a rollout on the device-generated walking plan against the oracle fed
+    with the plan read back from the device."""
+    from linearmpchumanoid_amd import trajectories
+    from oracle.pyoracle import Oracle
+    dt, th = 1e-3, 0.032
+    ctl = make_controller(3, dt, th, cfg2["zcom"], warm_start=1)
+    ctl.gen_jump(0.9, stance_time=0.4, flight_time=0.15)
+    g, p = ctl.get_refs(), trajectories.jump_plan(0.9, dt, stance_time=0.4, flight_time=0.15)
+    assert np.array_equal(g["phase"], p["phase"]) and np.array_equal(g["zmp_x"], p["zmp_x"]) and np.array_equal(g["zmp_y"], p["zmp_y"])
+    assert len(g["segs"]) == 0
+    ctl.gen_walk(0.6, num_steps=2, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.05)
+    xs = np.array([0.02, 0.035, 0.05])
+    ctl.set_xscale(xs)
+    plan = ctl.get_refs()
+    nt = 300
+    st = ctl.new_state(cfg2["q0"], np.zeros(30), t=0.0)
+    out, status, log = ctl.rollout(st, nt, log=True)
+    torch.cuda.synchronize()
+    log, status = log.cpu().numpy(), status.cpu().numpy()
+    assert (status[:, 2] == 0).all()
+    for i in range(3):
+        o = Oracle(sim_time=0.6, dt=dt, horizon_time=th, do_ik=True)
+        o.set_zcom(cfg2["zcom"])
+        o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+        o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
+        r = o.rollout(np.concatenate([cfg2["q0"], np.zeros(30)]), 0.0, nt, log=True)
+        assert status[i, 0] == r["k"][-1]
+        for tk in range(0, nt, 9):
+            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
+
+
 # ------------------------------------------------------------------------------- summary kernel, record files, N > 1 entry
 def test_summary_kernel_matches_the_host_form(cfg2):
     from linearmpchumanoid_amd import sharding
