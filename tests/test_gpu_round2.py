@@ -343,7 +343,7 @@ def test_config5_jump_schedule_full_size():
     dict(simulation_time=2.5, num_steps=4, time_per_step=0.5, ds_time=0.1, step_height=0.02, settle_time=0.3, first_support=1, foot_y=0.05),
     dict(simulation_time=1.0, num_steps=2, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.1, first_support=1, foot_y=0.05),
     dict(simulation_time=1.3, num_steps=7, time_per_step=0.17, ds_time=0.033, step_height=0.015, settle_time=0.0731, first_support=2, foot_y=0.045),
-    dict(simulation_time=0.35, num_steps=5, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.1, first_support=1, foot_y=0.05),  # plan ends beyond the sample grid
+    dict(simulation_time=0.56, num_steps=5, time_per_step=0.2, ds_time=0.05, step_height=0.02, settle_time=0.1, first_support=1, foot_y=0.05),  # the last swing is cut by the end of the sample grid
 ])
 def test_walk_generator_kernel_matches_the_host_plan(gait):
     """lmh_gen_walk (device kernel) against trajectories.walk_plan (host statement of the same plan): ZMP samples, support phase and
