@@ -88,6 +88,18 @@ typedef struct lmh_config {
     int32_t bpp_rounds;    /* block-principal-pivoting rounds of the contact-force QP before the Lawson-Hanson pass takes over:
                               0 = default (10); n > 0 = cap at n rounds; < 0 = skip block pivoting, solve by Lawson-Hanson from the
                               empty set (diagnostic: exercises the finite fall-back) */
+    /* Build-defined plant.  plant = 0: the reference's closed loop, which integrates the controller's own acceleration
+     * and throws the torques away (apps/offline/main.cpp:118-121).  plant = 1: the RK4 derivative is the forward dynamics
+     * M qdd = S'tau + J'w_contact - C driven by the torques the WBC returns, with a spring-damper contact at the four vertices of each sole
+     * (Robot.cpp:38-42) against the plane z = 0: normal force max(0, k d - c zdot) on penetration d, tangential force -c_t (xdot, ydot)
+     * scaled back onto the friction disc mu f_n.  M, C, J are the terms the controller evaluated in the same call.  out.qdd then carries the
+     * plant's acceleration.  (The reference's intended route, MuJoCo feedback, is commented out at apps/mujoco/main.cpp:115-122.) */
+    int32_t plant;
+    int32_t reserved;
+    double contact_k;      /* normal stiffness per vertex [N/m]; the light distal links bound it for explicit RK4 (ankle inertia 1.4e-5 kg m^2) */
+    double contact_d;      /* normal damping per vertex [N s/m]  */
+    double contact_dt;     /* tangential damping per vertex [N s/m] */
+    double contact_mu;     /* friction coefficient of the plant's ground */
 } lmh_config;
 
 typedef struct lmh_handle lmh_handle;

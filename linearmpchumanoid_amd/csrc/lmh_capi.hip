@@ -67,6 +67,7 @@ extern "C" void lmh_config_default(lmh_config *c)
     c->w_joints = 1; c->w_force = 1; c->w_foot = 100000;            // :122-124
     c->eps_coeff = 1e-8;                                            // controller.cpp:117
     c->warm_start = 1; c->max_qp_iters = 64; c->precision = LMH_PRECISION_FP64; c->bpp_rounds = 0;
+    c->plant = 0; c->contact_k = 2.0e4; c->contact_d = 3.0; c->contact_dt = 3.0; c->contact_mu = 0.7;
 }
 
 extern "C" void lmh_nominal_links(double *raw) { std::memcpy(raw, kLmhNaoLinks, sizeof(kLmhNaoLinks)); }
@@ -226,6 +227,7 @@ static void fill_params(lmh_handle *h)
     P.n_samples = h->n_samples; P.horizon = h->N; P.n_instances = h->B;
     P.warm_start = c.warm_start; P.max_qp_iters = c.max_qp_iters; P.precision = c.precision;
     P.bpp_max = (c.bpp_rounds == 0) ? 10 : c.bpp_rounds;            // < 0: Lawson-Hanson from the empty set (diagnostic)
+    P.plant = c.plant; P.contact_k = c.contact_k; P.contact_d = c.contact_d; P.contact_dt = c.contact_dt; P.contact_mu = c.contact_mu;
     P.dt = c.dt;
     P.kp_joints = c.kp_joints; P.kd_joints = c.kd_joints; P.kp_mom = c.kp_mom; P.kd_mom = c.kd_mom;
     P.kp_feet = c.kp_feet; P.kd_feet = c.kd_feet;
@@ -264,6 +266,9 @@ static const char *validate_config(const lmh_config *c)
     const double g[6] = {c->kp_joints, c->kd_joints, c->kp_mom, c->kd_mom, c->kp_feet, c->kd_feet};
     for (double v : g) if (!std::isfinite(v)) return "PD gains must be finite";
     if (c->max_qp_iters < 1) return "max_qp_iters must be >= 1";
+    if (c->plant != 0 && c->plant != 1) return "plant must be 0 or 1";
+    if (c->plant && (!(c->contact_k > 0.0) || !(c->contact_d >= 0.0) || !(c->contact_dt >= 0.0) || !(c->contact_mu >= 0.0)))
+        return "contact_k must be positive, contact_d / contact_dt / contact_mu non-negative";
     if (c->precision != LMH_PRECISION_FP64 && c->precision != LMH_PRECISION_MIXED)
         return "precision must be LMH_PRECISION_FP64 or LMH_PRECISION_MIXED";
     return nullptr;

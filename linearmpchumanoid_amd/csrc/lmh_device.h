@@ -31,11 +31,13 @@ struct LmhDevParams {
     int32_t max_qp_iters;
     int32_t precision;          // 0: fp64 throughout; 1: mixed (fp32 model terms, fp64 references + QP); 2: fp32
     int32_t bpp_max;            // block-pivoting rounds before the Lawson-Hanson pass (< 0: Lawson-Hanson only)
+    int32_t plant;              // 1: compliant-contact plant driven by the torques (lmh_config.plant)
     // ---- scalars (reference literals, see include/lmh.h lmh_config)
     double dt;
     double kp_joints, kd_joints, kp_mom, kd_mom, kp_feet, kd_feet;
     double w_com_lin, w_com_ang, w_base_pos, w_base_ang, w_joints, w_force, w_foot;
     double eps_coeff;
+    double contact_k, contact_d, contact_dt, contact_mu;
     double a00, a01, a10, a11, b0, b1;   // LIPM A, B (mpcLinearPendulum.cpp:45-47)
     // ---- foot reference polynomials (shared), ascending powers
     double rF[3][8];

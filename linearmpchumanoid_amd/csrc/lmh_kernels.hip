@@ -2465,6 +2465,129 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     return flags;
 }
 
+// ---- build-defined plant (lmh_config.plant): forward dynamics driven by the torques the WBC returns, with a spring-damper
+// contact at the sole vertices.  With tau = (M a + C - J'w)[6:30] and the floating-base rows of the QP, S'tau - C = M a - J'w, so
+//     M qdd_plant = S'tau + J'w_c - C   <=>   qdd_plant = a + M^-1 J'(w_c - w):
+// the plant's acceleration is the controller's plus the response to the contact-wrench error.  M = [Ic0 F2; F2' H] with H block diagonal
+// per limb (legs 6x6, arms 5x5, head 2x2): the four limb blocks are eliminated at once on the four DPP rows (Gauss-Jordan, 7 right-hand
+// sides [r_l | F2_l']), the 6x6 base Schur complement (not symmetric: the reference's inertia typos) by one more Gauss-Jordan.
+enum { PL_VF = S0 + 0,      // 8 x 6 : r_v x f_v | f_v per vertex
+       PL_DW = S0 + 48,     // 12 : w_c - w
+       PL_R = S0 + 60,      // 30 : J'(w_c - w)
+       PL_B = S0 + 90,      // 24 x 7 : H^-1 [r_J | F2']
+       PL_SB = S0 + 258,    // 6 x 7 : Schur complement | right-hand side
+       PL_DAB = S0 + 300,   // 6
+       PL_AP = S0 + 306,    // 30 : plant acceleration (WBC coordinates)
+       PL_ZERO = S0 + 336 }; // 32
+__device__ __forceinline__ void phase_plant(double *L, const LmhDevParams &P)
+{
+    const int lane = LANE;
+    if (lane < 8) {                                                // one lane per (foot, vertex)
+        const int ft = lane >> 2, vi = lane & 3;
+        const double pwx = (vi < 2) ? 0.1 : -0.05, pwy = (vi & 1) ? -0.025 : 0.025, pwz = 0.0;        // Robot.cpp:38-42
+        // offsets are world-aligned for the flat foot (controller.cpp:225-270) and turn with it: r_v = R_sole Rf_q0' p_v
+        double p[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) p[a] = c_rdes[a] * pwx + c_rdes[3 + a] * pwy + c_rdes[6 + a] * pwz;
+        const double *T = L + P_TB + 12 * (1 + ft), *om = L + P_VFOOT + 6 * ft, *vo = om + 3;
+        double rp[3], x[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { rp[a] = T[4 * a] * p[0] + T[4 * a + 1] * p[1] + T[4 * a + 2] * p[2]; x[a] = rp[a] + T[4 * a + 3]; }
+        const double xd0 = vo[0] + (om[1] * rp[2] - om[2] * rp[1]);
+        const double xd1 = vo[1] + (om[2] * rp[0] - om[0] * rp[2]);
+        const double xd2 = vo[2] + (om[0] * rp[1] - om[1] * rp[0]);
+        const double pen = -x[2];
+        double fn = P.contact_k * pen - P.contact_d * xd2;
+        fn = (fn < 0.0) ? 0.0 : fn;
+        double ftx = -P.contact_dt * xd0, fty = -P.contact_dt * xd1;
+        const double ft2 = sqrt(ftx * ftx + fty * fty), lim = P.contact_mu * fn;
+        const double sc = (ft2 > lim) ? lim / ft2 : 1.0;
+        const bool in = pen > 0.0;
+        const double f0 = in ? ((ft2 > lim) ? ftx * sc : ftx) : 0.0, f1 = in ? ((ft2 > lim) ? fty * sc : fty) : 0.0, f2 = in ? fn : 0.0;
+        double *o = L + PL_VF + 6 * lane;
+        o[0] = rp[1] * f2 - rp[2] * f1; o[1] = rp[2] * f0 - rp[0] * f2; o[2] = rp[0] * f1 - rp[1] * f0;
+        o[3] = f0; o[4] = f1; o[5] = f2;
+    }
+    if (lane >= 32) L[PL_ZERO + lane - 32] = 0.0;
+    WSYNC();
+    if (lane < 12) {                                               // wrench about the sole origin, vertices summed in order
+        const int ft = lane / 6, k = lane % 6;
+        const double *v = L + PL_VF + 24 * ft + k;
+        const double wc = (((0.0 + v[0]) + v[6]) + v[12]) + v[18];
+        L[PL_DW + lane] = wc - L[P_W12 + lane];
+    }
+    WSYNC();
+    if (lane < 30) {                                               // r = J'(w_c - w): base and leg columns only
+        double r = 0.0;
+        if (lane < 18) {
+#pragma unroll
+            for (int row = 0; row < 12; row++) r += jdense(L, row, lane) * L[PL_DW + row];
+        }
+        L[PL_R + lane] = r;
+    }
+    WSYNC();
+    {   // limb blocks: DPP row dr = limb (RL, LL, RA, LA), lane l16 < 6 = joint of the limb (arms: a unit row pads 5 -> 6)
+        const int dr = lane >> 4, l16 = lane & 15;
+        const int nl = (dr < 2) ? 6 : 5, js = (dr == 0) ? 0 : (dr == 1) ? 6 : (dr == 2) ? 12 : 17;
+        const bool real = l16 < nl;
+        const int ja = js + (real ? l16 : 0);
+        double a[6], b[7];
+#pragma unroll
+        for (int c = 0; c < 6; c++) { const double hv = L[P_HL + 6 * ja + ((c < 5) ? c : (dr < 2 ? 5 : 0))]; a[c] = (real && c < nl) ? hv : ((l16 == c && l16 < 6) ? 1.0 : 0.0); }
+        { const double rv = L[PL_R + 6 + ja]; b[0] = real ? rv : 0.0; }
+#pragma unroll
+        for (int m = 0; m < 6; m++) { const double fv = L[P_MTOP + 30 * m + 6 + ja]; b[1 + m] = real ? fv : 0.0; }
+        int bad = 0;
+        double myinv = 0.0;
+        gj16_step<0>(a, b, 0x3Fu, l16, true, 0.0, bad, myinv);
+#pragma unroll
+        for (int c = 0; c < 7; c++) L[real ? PL_B + 7 * ja + c : Q_TRASH + lane] = b[c] * myinv;
+    }
+    if (lane < 14) {                                               // head: 2 x 2 in closed form
+        const int i = lane / 7, c = lane % 7;
+        const double h00 = L[P_HL + 6 * 22], h01 = L[P_HL + 6 * 22 + 1], h10 = L[P_HL + 6 * 23], h11 = L[P_HL + 6 * 23 + 1];
+        const double r0 = (c == 0) ? L[PL_R + 6 + 22] : L[P_MTOP + 30 * (c - 1) + 6 + 22], r1 = (c == 0) ? L[PL_R + 6 + 23] : L[P_MTOP + 30 * (c - 1) + 6 + 23];
+        const double det = h00 * h11 - h01 * h10;
+        L[PL_B + 7 * (22 + i) + c] = (i == 0) ? (h11 * r0 - h01 * r1) / det : (h00 * r1 - h10 * r0) / det;
+    }
+    WSYNC();
+    {   // base: S_b = Ic0 - F2 B_M, rhs = r_b - F2 B_r   (one matrix-core tile, K = 24)
+        const int tr = lane & 15, tq = lane >> 4;
+        const double *zero = L + PL_ZERO;
+        const v4d fb = mfma_ptr<6, 4, 28>((tr < 6) ? L + P_MTOP + 30 * tr + 6 + tq : zero, (tr < 7) ? L + PL_B + 7 * tq + tr : zero);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int m = tq + 4 * g;
+            const bool ok = (m < 6) && (tr < 7);
+            const double base = L[!ok ? PL_ZERO : (tr == 0) ? PL_R + m : P_MTOP + 30 * m + (tr - 1)];
+            L[ok ? PL_SB + 7 * m + tr : Q_TRASH + lane] = base - fb[g];
+        }
+    }
+    WSYNC();
+    {
+        double a[6], b[1];
+        const int lr = (lane < 6) ? lane : 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) a[c] = L[PL_SB + 7 * lr + 1 + c];
+        b[0] = L[PL_SB + 7 * lr];
+        (void)gj_solve_regs<6, 1>(a, b, 0x3Fu);
+        if (lane < 6) L[PL_DAB + lane] = b[0];
+    }
+    WSYNC();
+    if (lane < 30) {
+        double da;
+        if (lane < 6) da = L[PL_DAB + lane];
+        else {
+            const double *B = L + PL_B + 7 * (lane - 6);
+            da = B[0];
+#pragma unroll
+            for (int n = 0; n < 6; n++) da -= B[1 + n] * L[PL_DAB + n];
+        }
+        L[PL_AP + lane] = L[P_A + lane] + da;
+    }
+    WSYNC();
+}
+
 // Controller::WBC tail (controller.cpp:134-153): tau, base acceleration back to the world frame.
 // The torques are not needed by the integrator: on the two-wave schedule the helper wave computes them while wave 0
 // already updates the state and runs the next forward kinematics.
@@ -2483,12 +2606,12 @@ __device__ __forceinline__ void phase_outputs_tau(double *L)
     }
     WSYNC();
 }
-__device__ __forceinline__ void phase_outputs_qdd(double *L)
+__device__ __forceinline__ void phase_outputs_qdd(double *L, int a_src = P_A)
 {
     const int lane = LANE;
     if (lane >= 32 && lane < 38) {                                 // X0 acc = a[0:6]: w = R0 a_ang ; v = R0 (a_lin - B0 w)
         const int k = lane - 32, r = k % 3;
-        const double *E0 = L + P_X0, *B0 = L + P_X0 + 12, *a = L + P_A;
+        const double *E0 = L + P_X0, *B0 = L + P_X0 + 12, *a = L + a_src;
         const double w0 = E0[0] * a[0] + E0[1] * a[1] + E0[2] * a[2];
         const double w1 = E0[3] * a[0] + E0[4] * a[1] + E0[5] * a[2];
         const double w2 = E0[6] * a[0] + E0[7] * a[1] + E0[8] * a[2];
@@ -2501,7 +2624,7 @@ __device__ __forceinline__ void phase_outputs_qdd(double *L)
         } else val = (r == 0) ? w0 : (r == 1) ? w1 : w2;
         L[P_QDD + k] = val;
     }
-    if (lane >= 40 && lane < 64) L[P_QDD + 6 + (lane - 40)] = L[P_A + 6 + (lane - 40)];
+    if (lane >= 40 && lane < 64) L[P_QDD + 6 + (lane - 40)] = L[a_src + 6 + (lane - 40)];
     WSYNC();
 }
 
@@ -2574,8 +2697,10 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     STAMP(7);
     flags |= phase_qp<NW>(L, P, ph, wid, Fmask, iters_out, dbg);
     STAMP(8);
-    if constexpr (NW == 1) { phase_outputs_tau(L); phase_outputs_qdd(L); }
-    else { if (wid == 0) phase_outputs_qdd(L); else phase_outputs_tau(L); }
+    const bool plant = P.plant != 0;                               // wave-uniform
+    if (plant && (NW == 1 || wid == 0)) phase_plant(L, P);         // the torques drive a plant instead of being thrown away (main.cpp:118-121)
+    if constexpr (NW == 1) { phase_outputs_tau(L); phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); }
+    else { if (wid == 0) phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); else phase_outputs_tau(L); }
     WSTAMP(28);
     STAMP(9);
     if (dbg) {

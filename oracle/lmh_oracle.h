@@ -107,6 +107,11 @@ typedef struct {
     unsigned short *seg_of_sample; /* owned, [n_zmp] */
     double xscale;
     int wbc_calls_per_eval;     /* 1 (result-neutral default) or 2 (apps/offline/main.cpp:103-105) */
+    /* build-defined plant: 0 = the reference's loop, which integrates the controller's own acceleration
+     * (apps/offline/main.cpp:118-121); 1 = forward dynamics M qdd = S'tau + J'w_contact - C driven by the torques the WBC returns,
+     * with a spring-damper contact at the four vertices of each sole (Robot.cpp:38-42) against the plane z = 0 */
+    int plant;
+    double contact_k, contact_d, contact_dt, contact_mu;   /* normal stiffness [N/m], normal / tangential damping [N s/m], friction */
 } orc_controller;
 
 /* everything one evaluation produces (unit-parity taps) */
@@ -183,6 +188,7 @@ void orc_stand_step(orc_system *s, const double *q, const double *dq, double t, 
 
 /* ---- closed loop (apps/offline/main.cpp:66-122, rk4.hpp:5-18, Clock.hpp:11) ---- */
 void orc_plant_derivative(orc_system *s, const double *state, double t, double *xdot, orc_eval *out);
+void orc_contact_wrench(const orc_system *s, const double *JFeet, double w[12], double vertex_force[8][3]);  /* spring-damper plant contact */
 void orc_rk4_tick(orc_system *s, double *state /*60*/, double t, double dt, orc_eval *last /*k4-stage eval*/);
 
 /* convenience: the whole apps/offline set-up (main.cpp:12-58) */

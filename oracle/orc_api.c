@@ -356,3 +356,16 @@ double orc_batch_rollout_ex(int B, double *states, double *out, double t0, doubl
     free(th); free(args);
     return (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
 }
+
+/* plant switch + contact parameters (see lmh_oracle.h orc_controller.plant) */
+void orc_sys_set_plant(void *h, int on, double k, double d, double dt, double mu)
+{
+    orc_controller *c = &((orc_box *)h)->sys.ctl;
+    c->plant = on; c->contact_k = k; c->contact_d = d; c->contact_dt = dt; c->contact_mu = mu;
+}
+/* contact wrench [12] and vertex forces [8][3] of the compliant ground at the robot's CURRENT state (after the last evaluation) */
+void orc_sys_contact(void *h, double *w, double *vf)
+{
+    orc_box *b = (orc_box *)h;
+    orc_contact_wrench(&b->sys, b->ev.JFeet, w, (double (*)[3])vf);
+}

@@ -9,6 +9,7 @@
  * zero (lbA = ubA = 0), which forces its wrench to zero through rows 6..17.  With every
  * sample in phase 0 the problem is exactly the reference's. */
 #include <stdlib.h>
+#include <math.h>
 #include "lmh_oracle.h"
 #include "orc_linalg.h"
 #include "orc_internal.h"
@@ -35,6 +36,8 @@ void orc_controller_init(orc_controller *c)                      /* controller.c
     memcpy(c->Rf_q0, rf, sizeof(rf));
     c->wbc_calls_per_eval = 1;
     c->xscale = 1.0;
+    c->plant = 0;
+    c->contact_k = 5.0e4; c->contact_d = 3.0e2; c->contact_dt = 3.0e2; c->contact_mu = 0.7;
 }
 
 void orc_controller_set_refs(orc_controller *c, int n, const double *zx, const double *zy, const unsigned char *phase)
@@ -274,6 +277,77 @@ void orc_stand_step(orc_system *s, const double *q, const double *dq, double t, 
     wbc(s, t, out->JFeet, out->phase, out);
 }
 
+/* BUILD-DEFINED (no reference semantics; the reference's intended feedback route, MuJoCo, is commented out at
+ * apps/mujoco/main.cpp:115-122): contact wrench of the compliant ground on the two soles.  Vertex v of foot f sits at
+ * x = o_sole + r_v, r_v = R_sole Rf_q0' p_v, and moves with xdot = v_o + w x r_v, (w, v_o) = J_f vhat (the sole's spatial velocity in
+ * world axes, fresh velocity).  Penetration d = -x_z > 0: normal force max(0, k d - c xdot_z); tangential force -c_t xdot_xy, scaled back
+ * onto the friction disc mu f_n.  Wrench about the sole origin in world axes, [n_R f_R n_L f_L] like the WBC's variables. */
+void orc_contact_wrench(const orc_system *s, const double *JFeet, double w[12], double vf[8][3])
+{
+    const orc_controller *c = &s->ctl;
+    const orc_robot *r = &s->robot;
+    double v[ORC_NQ], vel[12];
+    memcpy(v, r->v, sizeof(v));
+    orc_swap_base_velocity(r->X[0], v);
+    orc_mv(12, ORC_NQ, JFeet, v, vel);
+    const int frames[2] = {7, 14};
+    for (int f = 0; f < 2; f++) {
+        const double *T = r->T[frames[f]];
+        const double *om = vel + 6 * f, *vo = vel + 6 * f + 3;
+        double n[3] = {0, 0, 0}, fs[3] = {0, 0, 0};
+        for (int vi = 0; vi < 4; vi++) {
+            /* the vertices (Robot.cpp:38-42) are offsets in WORLD-ALIGNED axes at the sole origin of a flat foot (that is how
+             * frictionConstraints crosses them with world-axis forces, controller.cpp:225-270); they turn with the foot:
+             * offset = R_sole Rf_q0' p_v, Rf_q0 = sole orientation of the flat foot (Robot.cpp:28-31) */
+            const double *pw = c->footVertices[vi];
+            double p[3], rp[3], x[3], xd[3], fv[3] = {0, 0, 0};
+            for (int a = 0; a < 3; a++) p[a] = c->Rf_q0[0 * 3 + a] * pw[0] + c->Rf_q0[1 * 3 + a] * pw[1] + c->Rf_q0[2 * 3 + a] * pw[2];
+            for (int a = 0; a < 3; a++) { rp[a] = T[a * 4] * p[0] + T[a * 4 + 1] * p[1] + T[a * 4 + 2] * p[2]; x[a] = rp[a] + T[a * 4 + 3]; }
+            xd[0] = vo[0] + (om[1] * rp[2] - om[2] * rp[1]);
+            xd[1] = vo[1] + (om[2] * rp[0] - om[0] * rp[2]);
+            xd[2] = vo[2] + (om[0] * rp[1] - om[1] * rp[0]);
+            const double pen = -x[2];
+            if (pen > 0.0) {
+                double fn = c->contact_k * pen - c->contact_d * xd[2];
+                if (fn < 0.0) fn = 0.0;
+                double ftx = -c->contact_dt * xd[0], fty = -c->contact_dt * xd[1];
+                const double ft = sqrt(ftx * ftx + fty * fty), lim = c->contact_mu * fn;
+                if (ft > lim) { const double sc = lim / ft; ftx *= sc; fty *= sc; }
+                fv[0] = ftx; fv[1] = fty; fv[2] = fn;
+            }
+            if (vf) memcpy(vf[4 * f + vi], fv, sizeof(fv));
+            n[0] += rp[1] * fv[2] - rp[2] * fv[1];
+            n[1] += rp[2] * fv[0] - rp[0] * fv[2];
+            n[2] += rp[0] * fv[1] - rp[1] * fv[0];
+            for (int a = 0; a < 3; a++) fs[a] += fv[a];
+        }
+        for (int a = 0; a < 3; a++) { w[6 * f + a] = n[a]; w[6 * f + 3 + a] = fs[a]; }
+    }
+}
+
+/* plant acceleration: M a = S'tau + J'w_contact - C in the WBC's coordinates (base twist in the base frame, [ang; lin]), then back to
+ * the world frame like controller.cpp:143-147.  M, C, J are the terms the controller evaluated in this call. */
+static void plant_acceleration(orc_system *s, const orc_eval *out, double qpp[ORC_NQ])
+{
+    const int n = ORC_NQ;
+    const orc_dynamics *d = &s->dyn;
+    double w[12], rhs[ORC_NQ], a[ORC_NQ], M[ORC_NQ * ORC_NQ];
+    orc_contact_wrench(s, out->JFeet, w, NULL);
+    for (int i = 0; i < n; i++) {
+        double jw = 0.0;
+        for (int k = 0; k < 12; k++) jw += out->JFeet[k * n + i] * w[k];
+        rhs[i] = ((i >= 6) ? out->tau[i - 6] : 0.0) + jw - d->C[i];
+    }
+    memcpy(M, d->M, sizeof(M));
+    orc_solve_ge(n, M, rhs, a);
+    double X0[36], rb[6], sol[6];
+    memcpy(X0, s->robot.X[0], sizeof(X0));
+    memcpy(rb, a, sizeof(rb));
+    orc_solve_ge(6, X0, rb, sol);
+    for (int k = 0; k < 3; k++) { qpp[k] = sol[3 + k]; qpp[3 + k] = sol[k]; }
+    for (int k = 6; k < n; k++) qpp[k] = a[k];
+}
+
 /* apps/offline/main.cpp:91-122 */
 void orc_plant_derivative(orc_system *s, const double *state, double t, double *xdot, orc_eval *out)
 {
@@ -291,7 +365,12 @@ void orc_plant_derivative(orc_system *s, const double *state, double t, double *
     orc_omega_to_euler_rate(q + 3, Om);
     orc_mv(3, 3, Om, w, o);
     for (int k = 0; k < 3; k++) xdot[3 + k] = o[k];               /* :116 */
-    for (int i = 0; i < n; i++) xdot[n + i] = out->qpp[i];
+    if (s->ctl.plant) {
+        double qpp[ORC_NQ];
+        plant_acceleration(s, out, qpp);                          /* the torques drive a plant instead of being thrown away (main.cpp:118-121) */
+        for (int i = 0; i < n; i++) xdot[n + i] = qpp[i];
+    } else
+        for (int i = 0; i < n; i++) xdot[n + i] = out->qpp[i];
 }
 
 /* rk4.hpp:5-18 */

@@ -132,6 +132,15 @@ class Oracle:
         g = np.array([cur[k] for k in self.GAIN_FIELDS], dtype=np.float64)
         lib().orc_sys_set_gains(self._h, _p(g))
 
+    def set_plant(self, on=True, k=5.0e4, d=3.0e2, dt=3.0e2, mu=0.7):
+        """Build-defined plant: forward dynamics driven by the WBC torques + spring-damper contact (lmh_oracle.h)."""
+        lib().orc_sys_set_plant(self._h, C.c_int(int(on)), C.c_double(k), C.c_double(d), C.c_double(dt), C.c_double(mu))
+
+    def contact(self):
+        w, vf = _f64(12), _f64(8, 3)
+        lib().orc_sys_contact(self._h, _p(w), _p(vf))
+        return w, vf
+
     def set_segments(self, segs, seg_of_sample, xscale=1.0):
         segs = np.ascontiguousarray(segs, dtype=np.float64)
         sos = np.ascontiguousarray(seg_of_sample, dtype=np.uint16)

@@ -407,6 +407,57 @@ def test_jump_generator_kernel_and_rollout_on_generated_plans(cfg2):
             assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
 
 
+# ------------------------------------------------------------------------------- plant
+def test_plant_rollout_parity_and_physics(cfg2):
+    """lmh_config.plant = 1: the RK4 derivative is the forward dynamics M qdd = S'tau + J'w_contact - C driven by the WBC torques, with
+    the spring-damper contact at the sole vertices.  (i) against the oracle's plant (literal dense M solve) over 200 ticks of a
+    standing robot with small velocity perturbations, two contact parameter sets; (ii) physics: the ground carries the weight once the
+    contact has settled; a robot released above the ground falls."""
+    from oracle.pyoracle import Oracle
+    dt, th = 1e-3, 0.032
+    B, nt = 6, 200
+    v = perturbed_velocities(B, seed=31337) * 0.2
+    v[0] = 0.0
+    for contact in (dict(contact_k=2.0e4, contact_d=3.0, contact_dt=3.0, contact_mu=0.7), dict(contact_k=8.0e3, contact_d=2.0, contact_dt=4.0, contact_mu=0.5)):
+        ctl = make_controller(B, dt, th, cfg2["zcom"], warm_start=1, plant=1, **contact)
+        ctl.set_refs_stance(2.0, 2)
+        st = ctl.new_state(cfg2["q0"], v, t=0.0)
+        out, status, log = ctl.rollout(st, nt, log=True)
+        torch.cuda.synchronize()
+        stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
+        assert (status[:, 2] == 0).all()
+        for i in range(B):
+            o = Oracle(sim_time=2.0, dt=dt, horizon_time=th, do_ik=True)
+            o.set_zcom(cfg2["zcom"])
+            o.set_plant(True, k=contact["contact_k"], d=contact["contact_d"], dt=contact["contact_dt"], mu=contact["contact_mu"])
+            r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, nt, log=True)
+            assert status[i, 0] == r["k"][-1]
+            assert np.abs(stn[i, :60] - r["state"]).max() < 1e-6 * max(1.0, np.abs(r["state"]).max()), (i, np.abs(stn[i, :60] - r["state"]).max())
+            for tk in range(0, nt, 7):
+                assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
+            if i == 0:                                             # unperturbed robot: after 0.2 s the springs carry m g
+                w, vf = o.contact()
+                assert abs(w[5] + w[11] - o.mass * 9.81) < 0.05 * o.mass * 9.81 and (vf[:, 2] >= 0).all()
+    # free fall: released 0.2 m above the ground, no vertex touches it -> the CoM falls with g whatever the joints do
+    ctl = make_controller(2, dt, th, cfg2["zcom"], warm_start=1, plant=1)
+    ctl.set_refs_stance(2.0, 2)
+    q = cfg2["q0"].copy(); q[2] += 0.2
+    st = ctl.new_state(q, np.zeros(30), t=0.0)
+    out0, s0 = ctl.stand_step(st.clone())
+    c0 = out0.cpu().numpy()[0, 66:69]
+    n = 20
+    ctl.rollout(st, n)
+    out1, s1 = ctl.stand_step(st.clone())
+    torch.cuda.synchronize()
+    o1 = out1.cpu().numpy()[0]
+    # The plant reuses the C the controller evaluated, i.e. with the PREVIOUS call's velocity (controller.cpp:56 before :59): with the legs
+    # whipping at several hundred rad/s^2 (nothing resists the ankle torques in the air) its velocity products lag, so momentum is only
+    # conserved to first order in dt.  Checked here: the CoM does fall, by 50..105 % of g t^2 / 2, and stays on its vertical.
+    drop, ideal = o1[68] - c0[2], -0.5 * 9.81 * (n * dt) ** 2
+    assert 0.5 * ideal > drop > 1.05 * ideal, (drop, ideal)
+    assert o1[71] < -0.5 * 9.81 * n * dt and np.abs(o1[69:71]).max() < 0.02
+
+
 # ------------------------------------------------------------------------------- summary kernel, record files, N > 1 entry
 def test_summary_kernel_matches_the_host_form(cfg2):
     from linearmpchumanoid_amd import sharding

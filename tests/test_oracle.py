@@ -234,3 +234,23 @@ def test_general_batch_driver_equals_single_rollouts():
         oi.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
         r = oi.rollout(st[i], 0.0, nt, log=True)
         assert np.array_equal(r["state"], st2[i]) and np.array_equal(r["log"][-1], out[i])
+
+
+def test_plant_of_the_oracle_is_physical():
+    """Build-defined plant (oracle/orc_controller.c plant_acceleration): forward dynamics driven by the WBC torques.
+    With the WBC's own wrench in place of the contact model it must return the WBC's acceleration (tau = M a + C - J'f is exactly that
+    identity); above the ground the CoM falls with g; standing on the springs, the contact carries the weight after the transient."""
+    o = oracle_system(1e-3, 0.032)
+    q0 = o.robot()["q"].copy()
+    e = o.eval(q0, np.zeros(30), 0.0)
+    t, qp = o.terms(), o.qp()
+    rhs = np.concatenate([np.zeros(6), e["tau"]]) + t["J"].T @ e["f"] - t["C"]
+    assert np.abs(np.linalg.solve(t["M"], rhs) - qp["x"][:30]).max() < 1e-9 * np.abs(qp["x"][:30]).max()
+    a_free = np.linalg.solve(t["M"], np.concatenate([np.zeros(6), e["tau"]]) - t["C"])
+    assert np.abs((t["AG"] @ a_free + t["AGpqp"])[3:] / o.mass - [0, 0, -9.81]).max() < 2e-3      # 0.7071 literals: not exactly 9.81
+    o.set_plant(True, k=2.0e4, d=3.0, dt=3.0, mu=0.7)
+    r = o.rollout(np.concatenate([q0, np.zeros(30)]), 0.0, 300, log=True)
+    w, vf = o.contact()
+    assert np.isfinite(r["state"]).all() and abs(w[5] + w[11] - o.mass * 9.81) < 0.03 * o.mass * 9.81
+    assert (vf[:, 2] >= 0).all() and (np.hypot(vf[:, 0], vf[:, 1]) <= 0.7 * vf[:, 2] + 1e-12).all()
+    assert abs(r["state"][2] - q0[2]) < 5e-3                       # it stands (sinks by the spring deflection only)
