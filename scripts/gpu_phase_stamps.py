@@ -48,7 +48,7 @@ ss = d[:, 3900:3915]
 def seg(a, b): return (b - a).mean()
 rows = [("fk:sincos", st_[:,0], ss[:,0]), ("fk:Lc+T0 build", ss[:,0], ss[:,1]), ("fk:chain 8 steps", ss[:,1], st_[:,1]),
         ("comx:CoM", st_[:,1], ss[:,2]), ("comx:E,p", ss[:,2], ss[:,3]), ("comx:B", ss[:,3], ss[:,4]), ("comx:copies,vhat", ss[:,4], st_[:,2]),
-        ("ne:base+vel sweep", st_[:,3], ss[:,5]), ("ne:acc sweep", ss[:,5], ss[:,6]), ("ne:forces", ss[:,6], ss[:,7]), ("ne:backward", ss[:,7], ss[:,8]), ("ne:base,C,Jpqp", ss[:,8], st_[:,4]),
+        ("ne:vel + acc sweeps", st_[:,3], ss[:,6]), ("ne:forces", ss[:,6], ss[:,7]), ("ne:backward", ss[:,7], ss[:,8]), ("ne:base,C,Jpqp", ss[:,8], st_[:,4]),
         ("crba:init", st_[:,4], ss[:,9]), ("crba:levels", ss[:,9], ss[:,10]), ("crba:roots", ss[:,10], ss[:,11]), ("crba:joint cols", ss[:,11], st_[:,5]),
         ("refs:AG", st_[:,6], ss[:,12]), ("refs:h,vfoot,pdj", ss[:,12], ss[:,13]), ("refs:mpc", ss[:,13], ss[:,14]), ("refs:pd mom/feet", ss[:,14], st_[:,7])]
 for n, a, b in rows:

@@ -29,9 +29,10 @@ phase = host["phase"][int(s[0, 0])] if host["phase"] is not None else 0
 nF = np.array([bin((~int(x)) & 0xFFFFFFFF).count("1") for x in s[:, 3]])
 print(f"config {cfgno}  B {B}  after {pre} ticks  k {int(s[0,0])}  support phase {int(phase)}  qp iters mean {s[:,1].mean():.2f} max {s[:,1].max()}  |F| mean {nF.mean():.1f}")
 names = {0: "start", 1: "fk | kinv+refs_prepare done", 2: "  joined", 3: "com_x share done", 4: "  joined", 5: "tree share done (NE+Jac | CRBA)", 6: "  joined",
-         7: "refs share done", 8: "  joined", 10: "qp fills done", 11: "  joined", 12: "Cm | V tile done", 13: "  joined", 14: "w0: rhs fix-up done",
-         15: "w0: LDL 15x15 done", 16: "  joined", 17: "Y tile done", 18: "  joined", 19: "w0: S tile done", 20: "w0: Si done", 21: "w0: T1 done",
+         7: "refs share done", 8: "  joined", 10: "qp fills done", 11: "  joined", 12: "Cm | V tile done", 13: "  joined", 14: "w0: rows of Cm, V loaded",
+         15: "w0: 15x15 solve done | w1: Z, Mb bp' tiles", 16: "  joined", 17: "w1: Y tiles done", 18: "set-up done (w0: qv | w1: Y)", 19: "w0: S tile done", 20: "w0: Si done", 21: "w0: T1 done",
          22: "w0: W,h done", 23: "w0: qv done", 24: "w0: cone start", 25: "w0: cone done", 26: "recovery done | w1 waiting since", 27: "  joined", 28: "outputs done"}
+print("(debug kernel: it also forms the 32 x 32 cone Hessian for its dump, ~5.7k cycles inside 'cone'; stamps cost ~70 cycles each)")
 print("%-38s %10s %10s %12s" % ("stamp (cycles from the start)", "wave 0", "wave 1", "barrier wait"))
 prev = None
 for i in sorted(names):
@@ -43,7 +44,7 @@ for i in sorted(names):
     print("%-38s %10.0f %10.0f %12s" % (names[i], v0, v1, wait))
     prev = (v0, v1)
 for i, n in ((30, "cone: entry"), (31, "cone: qmax done"), (32, "cone(all free): W rows loaded"), (33, "cone(all free): 12x12 solve done"), (34, "cone(all free): c = Gpinv u done"), (35, "cone(all free): feasibility test done"),
-             (40, "last LDL (N<=16): start"), (41, "  forward + D^-1 done"), (42, "  L rows parked"), (43, "  backward done")):
+             (40, "last LDL' (N<=16): start"), (41, "  forward + D^-1 done"), (42, "  L rows parked"), (43, "  backward done")):
     if w0[:, i].any():
         print("%-38s %10.0f" % (n, a0[i]))
 tot = (w0[:, 28] - w0[:, 0])
