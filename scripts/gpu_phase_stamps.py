@@ -28,21 +28,29 @@ print("total cycles/eval: mean %.0f  p50 %.0f  max %.0f" % (tot.mean(), np.media
 for n, c in zip(names, dur.mean(axis=0)):
     print("  %-14s %8.0f cycles  %5.1f%%" % (n, c, 100 * c / tot.mean()))
 q = d[:, 4010:4014]
-sub = np.stack([q[:, 0] - st_[:, 7], q[:, 1] - q[:, 0], q[:, 2] - q[:, 1], q[:, 3] - q[:, 2], st_[:, 8] - q[:, 3]], axis=1).mean(axis=0)
-for n, c in zip(['qp:woodbury', 'qp:schur+W', 'qp:WG,P', 'qp:cone solve', 'qp:recover'], sub):
-    print("  %-14s %8.0f cycles  %5.1f%%" % (n, c, 100 * c / tot.mean()))
-# per-solve stamps inside the cone QP loop (instruction-cache warm-up shows as solve 1 >> solve 2..)
+# qp_setup15 stamps: 4070 fills done, 4074 15x15 solve (+ Z, Mb bp' tiles) done, 4011 [W|h] done, 4012 cone start, 4013 cone done.
+# A row is printed only when both of its stamps were written by this build (a stamp the kernel never wrote reads 0).
+def row(name, a, b):
+    ok = (a != 0) & (b != 0)
+    if ok.all():
+        c = (b - a).mean()
+        print("  %-26s %8.0f cycles  %5.1f%%" % (name, c, 100 * c / tot.mean()))
+    else:
+        print("  %-26s (stamp not written by this build)" % name)
+w = d[:, 4070:4075]
+row('qp:fills', st_[:, 7], w[:, 0])
+row('qp:Cm,V + 15x15 solve + Z', w[:, 0], w[:, 4])
+row('qp:S, S^-1, T1, [W|h]', w[:, 4], q[:, 1])
+row('qp:qv, Y join', q[:, 1], q[:, 2])
+row('qp:cone solve', q[:, 2], q[:, 3])
+row('qp:recover', q[:, 3], st_[:, 8])
+# per-solve stamps inside the cone QP loop
 for itn in range(1, 7):
     m = s[:, 1] >= itn
     if m.sum() == 0: break
+    if not (d[m, 4020 + 2 * itn] != 0).all(): continue     # the all-free fast path does not enter the loop
     dur_i = d[m, 4021 + 2 * itn] - d[m, 4020 + 2 * itn]
-    print("  cone solve #%d: n=%4d  mean %7.0f cycles  (mean |F| %.1f)" % (itn, m.sum(), dur_i.mean(), d[m, 4050 + itn].mean()))
-
-w = d[:, 4070:4075]
-names_w = ['wb:U,bp fill', 'wb:Cm,V mfma', 'wb:LDL', 'wb:Y mfma']
-t_w = np.stack([w[:,0]-st_[:,7], w[:,3]-w[:,0], w[:,4]-w[:,3], q[:,0]-w[:,4]], axis=1).mean(axis=0)
-for n, c in zip(names_w, t_w):
-    print("  %-14s %8.0f cycles" % (n, c))
+    print("  cone loop solve #%d: n=%4d  mean %7.0f cycles  (mean |F| %.1f)" % (itn, m.sum(), dur_i.mean(), d[m, 4050 + itn].mean()))
 
 ss = d[:, 3900:3915]
 def seg(a, b): return (b - a).mean()
