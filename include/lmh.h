@@ -49,6 +49,8 @@ extern "C" {
 #define LMH_FLAG_NONFINITE 2      /* NaN/Inf in the solution (reference aborts, controller.cpp:448-466) */
 #define LMH_FLAG_ZMP_RANGE 4      /* preview window [k, k+N] left the reference arrays */
 #define LMH_FLAG_NOT_SPD 8        /* a Cholesky pivot was not positive */
+#define LMH_FLAG_QP_FP64_ROUTE 16 /* LMH_PRECISION_FP32 only, informational: a contact-force solve of this instance met a rank-deficient free set
+                                   * (or the Lawson-Hanson pass) and went the fp64 general route -- that system (cond ~1e13) has no fp32 form */
 
 /* support phase per preview sample (build-defined extension; reference: Task.hpp:9-13 SupportFoot) */
 #define LMH_PHASE_DOUBLE 0
@@ -59,6 +61,7 @@ extern "C" {
 /* arithmetic of the model-term phases (BASELINE config 5 tolerance sweep; build-defined, the reference is fp64 only) */
 #define LMH_PRECISION_FP64 0
 #define LMH_PRECISION_MIXED 1
+#define LMH_PRECISION_FP32 2      /* model terms AND the whole-body QP in fp32 (one fp64 residual refinement of the 12 x 12 contact solve) */
 #define LMH_SUMMARY_WIDTH 16      /* end-of-run summary record (doubles per instance), see lmh_make_summary */
 
 enum {
@@ -84,7 +87,10 @@ typedef struct lmh_config {
     int32_t warm_start;    /* 1: start the active set from the previous evaluation's (same minimiser) */
     int32_t max_qp_iters;
     int32_t precision;     /* LMH_PRECISION_FP64 (reference arithmetic) | LMH_PRECISION_MIXED: model terms (kinematics, C, M, J) in
-                              fp32 arithmetic, references + QP in fp64; k = int(t/dt) is computed in fp64 in every mode */
+                              fp32 arithmetic, references + QP in fp64 | LMH_PRECISION_FP32: the QP too (Woodbury core, Schur
+                              complement, push-through contact solves with one fp64 residual refinement; a rank-deficient contact set
+                              falls back to the fp64 general route and raises LMH_FLAG_QP_FP64_ROUTE).  References, RK4 state and
+                              k = int(t/dt) are fp64 in every mode */
     int32_t bpp_rounds;    /* block-principal-pivoting rounds of the contact-force QP before the Lawson-Hanson pass takes over:
                               0 = default (10); n > 0 = cap at n rounds; < 0 = skip block pivoting, solve by Lawson-Hanson from the
                               empty set (diagnostic: exercises the finite fall-back) */

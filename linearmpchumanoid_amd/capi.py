@@ -23,9 +23,10 @@ FLAG_QP_MAXITER = 1
 FLAG_NONFINITE = 2
 FLAG_ZMP_RANGE = 4
 FLAG_NOT_SPD = 8
+FLAG_QP_FP64_ROUTE = 16
 
 PHASE_DOUBLE, PHASE_RIGHT, PHASE_LEFT, PHASE_FLIGHT = 0, 1, 2, 3
-PRECISION_FP64, PRECISION_MIXED = 0, 1   # lmh_config.precision (include/lmh.h)
+PRECISION_FP64, PRECISION_MIXED, PRECISION_FP32 = 0, 1, 2   # lmh_config.precision (include/lmh.h)
 SUMMARY_WIDTH = 16
 
 # every symbol include/lmh.h declares (checked by tests/test_abi.py)

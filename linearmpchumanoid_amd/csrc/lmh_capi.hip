@@ -269,8 +269,8 @@ static const char *validate_config(const lmh_config *c)
     if (c->plant != 0 && c->plant != 1) return "plant must be 0 or 1";
     if (c->plant && (!(c->contact_k > 0.0) || !(c->contact_d >= 0.0) || !(c->contact_dt >= 0.0) || !(c->contact_mu >= 0.0)))
         return "contact_k must be positive, contact_d / contact_dt / contact_mu non-negative";
-    if (c->precision != LMH_PRECISION_FP64 && c->precision != LMH_PRECISION_MIXED)
-        return "precision must be LMH_PRECISION_FP64 or LMH_PRECISION_MIXED";
+    if (c->precision != LMH_PRECISION_FP64 && c->precision != LMH_PRECISION_MIXED && c->precision != LMH_PRECISION_FP32)
+        return "precision must be LMH_PRECISION_FP64, LMH_PRECISION_MIXED or LMH_PRECISION_FP32";
     return nullptr;
 }
 

@@ -173,6 +173,19 @@ enum {
     Q_LS = S0 + 2142,  // 6 x 7 scratch of the S^-1 step
     Q_ZERO = S0 + 2184, // 32 zeros
     Q_TRASH = S0 + 2216, // 64: where the lanes outside a tile's valid range store
+    // ---- fp32 QP (LMH_PRECISION_FP32, phase_qp_f32): plain row-major arrays of float-valued slots
+    F_U = S0 + 0,      // 18 x 30
+    F_A = S0 + 540,    // 18 x 25 : [Cm | V] augmented system
+    F_BP = S0 + 1016,  // 30 x 7  : bp' = [-qref | D^-1 Mb']
+    F_BQ = S0 + 1226,  // 30 : -qref + D^-1 U' Om beta (V's g column)
+    F_S = S0 + 1260,   // 6 x 12 : [S | I]
+    F_OB = S0 + 1382,  // Om*beta (18) | 1/Om (18) | beta (18)
+    F_T1 = S0 + 1436,  // 12 x 6
+    F_K = S0 + 1520,   // 2 x 6 x 12 : [K_f | I] per foot
+    F_KI = S0 + 1670,  // 2 x 36 : K_f^-1
+    F_PT = S0 + 1750,  // 12 x 25 : [W + eps K^-1 | h | I]
+    F_M = S0 + 2060,   // 12 x 12 : copy of the push-through matrix for the residual
+    F_V = S0 + 2210,   // small vectors: w0 (12) | r (12) | w (12) | y (12)
     // ---- phase C (cone QP)
     C_WG = S0 + 0,    // 12 x 32
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
@@ -1798,14 +1811,242 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
     return 1;
 }
 
+// ================================================================== fp32 QP (LMH_PRECISION_FP32, BASELINE config 5's tolerance sweep)
+// The same algebra as qp_setup15 / qp_setup + the push-through cone solves, every product, elimination and accumulation in fp32
+// (the LDS slots stay 8 bytes wide and hold float values: no second layout).  Written for the sweep, not for speed: plain loops, one wave,
+// in-LDS Gauss-Jordan.  What stays fp64: the references (clock / PD laws), the residual of the one refinement step of the 12 x 12
+// push-through system, the sign tests of the active-set iteration, and the general P_FF route for a rank-deficient contact set
+// (cond ~1e13: not representable in fp32; the instance is marked LMH_FLAG_QP_FP64_ROUTE).
+__device__ __forceinline__ float ldf(const double *L, int i) { return (float)L[i]; }
+
+// Gauss-Jordan on an augmented row-major array A (n rows, row stride ld; columns [0, n) the SPD matrix, [n, n + m) right-hand sides; on exit
+// those columns hold the solutions).  Rows / columns whose bit is clear in `live` are skipped (their solutions are 0).  A pivot that is not
+// above rel * (its original diagonal) marks the system singular.  Returns non-zero (wave-uniform) in that case.
+__device__ __forceinline__ int gj_lds_f32(double *A, int n, int m, int ld, unsigned live, float rel)
+{
+    const int lane = LANE;
+    int bad = 0;
+    WSYNC();
+    const float d0 = ldf(A, ((lane < n) ? lane : 0) * (ld + 1));
+    for (int j = 0; j < n; j++) {
+        if (!((live >> j) & 1u)) continue;                         // wave-uniform
+        WSYNC();
+        float d = ldf(A, j * ld + j);
+        const float dj0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), j));
+        if (!(d > rel * dj0) || !(d > 0.0f)) { bad = 1; d = 1.0f; }
+        const float inv = 1.0f / d;
+        const int cols = n + m - 1 - j, total = n * cols;
+        for (int e = lane; e < total; e += 64) {
+            const int i = e / cols, c = j + 1 + (e - i * cols);
+            if (i != j && ((live >> i) & 1u)) {
+                const float f = ldf(A, i * ld + j) * inv;
+                A[i * ld + c] = (double)fmaf(-f, ldf(A, j * ld + c), ldf(A, i * ld + c));
+            }
+        }
+    }
+    WSYNC();
+    for (int e = lane; e < n * m; e += 64) {
+        const int i = e / m, r = e - i * m;
+        const bool on = (live >> i) & 1u;
+        const float dd = ldf(A, i * ld + i);
+        A[i * ld + n + r] = on ? (double)(ldf(A, i * ld + n + r) / ((dd > 0.0f) ? dd : 1.0f)) : 0.0;
+    }
+    WSYNC();
+    return bad;
+}
+
+// controller.cpp:94-132 + the equality blocks of :388-436 down to W, h, qv, in fp32.  nU = 15 or 18 rows of U = [AG ; J] (run time).
+__device__ __forceinline__ int qp_setup_f32(double *L, const LmhDevParams &P)
+{
+    const int lane = LANE;
+    int flags = 0;
+    const int nU = (P.w_com_ang == 0.0) ? 15 : 18, r0 = 18 - nU, nA = nU + 7;
+    const float idp = 1.0f / (float)P.w_base_pos, ida = 1.0f / (float)P.w_base_ang, idj = 1.0f / (float)P.w_joints;
+    auto iD = [=](int i) { return (i < 3) ? idp : (i < 6) ? ida : idj; };
+    WSYNC();
+    for (int e = lane; e < nU * 30; e += 64) {
+        const int r = r0 + e / 30, c = e % 30;
+        L[F_U + e] = (double)(float)((r < 6) ? L[P_AG + 30 * r + c] : jdense(L, r - 6, c));
+    }
+    if (lane < nU) {
+        const int rr = r0 + lane;
+        const float om = (float)((rr < 3) ? P.w_com_ang : (rr < 6) ? P.w_com_lin : P.w_foot);
+        const float beta = (rr < 6) ? (ldf(L, P_AGPQP + rr) - ldf(L, P_HREF + rr)) : (ldf(L, P_JPQP + rr - 6) - ldf(L, P_FREF + rr - 6));
+        L[F_OB + lane] = (double)(om * beta);
+        L[F_OB + 18 + lane] = (double)(1.0f / om);
+        L[F_OB + 36 + lane] = (double)beta;
+    }
+    for (int e = lane; e < 210; e += 64) {
+        const int i = e / 7, c = e % 7;
+        L[F_BP + e] = (double)((c == 0) ? -ldf(L, P_QREF + i) : ldf(L, P_MTOP + 30 * (c - 1) + i) * iD(i));
+    }
+    WSYNC();
+    if (lane < 30) {                                               // q = D^-1 U' Om beta
+        float q = 0.0f;
+        for (int r = 0; r < nU; r++) q = fmaf(ldf(L, F_U + 30 * r + lane), ldf(L, F_OB + r), q);
+        L[F_BQ + lane] = (double)fmaf(q, iD(lane), ldf(L, F_BP + 7 * lane));
+    }
+    WSYNC();
+    for (int e = lane; e < nU * nA; e += 64) {                     // [Cm | V] = [Om^-1 + U D^-1 U' | U (bp'_g + q), U bp'_M]
+        const int r = e / nA, c = e - r * nA;
+        float sacc;
+        if (c < nU) {
+            sacc = (r == c) ? ldf(L, F_OB + 18 + r) : 0.0f;
+            for (int i = 0; i < 30; i++) sacc = fmaf(ldf(L, F_U + 30 * r + i) * iD(i), ldf(L, F_U + 30 * c + i), sacc);
+        } else {
+            const int n = c - nU;
+            sacc = 0.0f;
+            for (int i = 0; i < 30; i++) sacc = fmaf(ldf(L, F_U + 30 * r + i), (n == 0) ? ldf(L, F_BQ + i) : ldf(L, F_BP + 7 * i + n), sacc);
+        }
+        L[F_A + 25 * r + c] = (double)sacc;
+    }
+    if (gj_lds_f32(L + F_A, nU, 7, 25, (1u << nU) - 1u, 0.0f)) flags |= LMH_FLAG_NOT_SPD;
+    if (lane < nU) L[F_A + 25 * lane + nU] = (double)(ldf(L, F_A + 25 * lane + nU) - ldf(L, F_OB + lane));     // t'' = t_g - ob
+    WSYNC();
+    for (int e = lane; e < 210; e += 64) {                         // Y = bp' - D^-1 U' t''  (stored transposed)
+        const int n = e / 30, i = e % 30;
+        float sacc = 0.0f;
+        for (int r = 0; r < nU; r++) sacc = fmaf(ldf(L, F_U + 30 * r + i), ldf(L, F_A + 25 * r + nU + n), sacc);
+        L[P_YT + e] = (double)fmaf(-sacc, iD(i), ldf(L, F_BP + 7 * i + n));
+    }
+    WSYNC();
+    if (lane < 42) {                                               // S | d = Mb Y
+        const int m = lane / 7, n = lane % 7;
+        float sacc = 0.0f;
+        for (int i = 0; i < 30; i++) sacc = fmaf(ldf(L, P_MTOP + 30 * m + i), ldf(L, P_YT + 30 * n + i), sacc);
+        if (n == 0) L[P_D6 + m] = (double)(ldf(L, P_C + m) - sacc);
+        else L[F_S + 12 * m + n - 1] = (double)sacc;
+    }
+    if (lane >= 64 - 36) { const int e = lane - (64 - 36), i = e / 6, j = e % 6; L[F_S + 12 * i + 6 + j] = (i == j) ? 1.0 : 0.0; }
+    if (gj_lds_f32(L + F_S, 6, 6, 12, 0x3Fu, 0.0f)) flags |= LMH_FLAG_NOT_SPD;
+    if (lane < 36) { const int i = lane / 6, j = lane % 6; L[P_SI + lane] = (double)(0.5f * (ldf(L, F_S + 12 * i + 6 + j) + ldf(L, F_S + 12 * j + 6 + i))); }
+    WSYNC();
+    for (int e = lane; e < 72; e += 64) {                          // T1 = Jb S^-1
+        const int row = e / 6, k = e % 6;
+        float sacc = 0.0f;
+        for (int j = 0; j < 6; j++) sacc = fmaf((float)jdense(L, row, j), ldf(L, P_SI + 6 * j + k), sacc);
+        L[F_T1 + e] = (double)sacc;
+    }
+    WSYNC();
+    for (int e = lane; e < 156; e += 64) {                         // [W | h] = [w_force I + T1 Jb' | T1 d]
+        const int m = e / 13, n = e % 13;
+        float sacc = (m == n) ? (float)P.w_force : 0.0f;
+        for (int k = 0; k < 6; k++) sacc = fmaf(ldf(L, F_T1 + 6 * m + k), (n < 12) ? (float)jdense(L, (n < 12) ? n : 0, k) : ldf(L, P_D6 + k), sacc);
+        L[(n < 12) ? F_M + 12 * m + n : P_H12 + m] = (double)sacc;
+    }
+    WSYNC();
+    for (int e = lane; e < 144; e += 64) { const int m = e / 12, n = e % 12; L[P_W + e] = (double)(0.5f * (ldf(L, F_M + 12 * m + n) + ldf(L, F_M + 12 * n + m))); }
+    if (lane < 32) {
+        // qv = G' h, accumulated in fp64 from the fp32 h: only the general route (fp64) and the tolerance scale read it, and that route
+        // needs qv_F in range(G_F') to ~eps_coeff relative (P_FF has eigenvalues eps_coeff on null(G_F): a 1e-7 rounding of qv would come
+        // back multiplied by 1e8)
+        const int o = 6 * (lane / 16);
+        double sacc = 0.0;
+        for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
+        L[P_QV + lane] = sacc;
+    }
+    WSYNC();
+    return flags;
+}
+
+// (W + eps Ki) w = h on the rows of `live` in fp32 with one refinement step (residual accumulated in fp64, correction through the fp32
+// inverse that the same Gauss-Jordan pass produced).  Ki = 2 x 36 (one 6 x 6 block per foot).  The result goes to L[F_V + 24 ..].
+__device__ __forceinline__ int pushthrough_solve_f32(double *L, const double *Ki, float eps, unsigned live)
+{
+    const int lane = LANE;
+    WSYNC();
+    for (int e = lane; e < 12 * 25; e += 64) {
+        const int i = e / 25, c = e % 25;
+        float v;
+        if (c < 12) {
+            v = ldf(L, P_W + 12 * i + c);
+            if (c / 6 == i / 6) v = fmaf(eps, (float)Ki[36 * (i / 6) + 6 * (i % 6) + c % 6], v);
+            L[F_M + 12 * i + c] = (double)v;
+        } else v = (c == 12) ? ldf(L, P_H12 + i) : ((c - 13 == i) ? 1.0f : 0.0f);
+        L[F_PT + e] = (double)v;
+    }
+    const int bad = gj_lds_f32(L + F_PT, 12, 13, 25, live, 0.0f);
+    if (lane < 12) {
+        double r = 0.0;
+        if ((live >> lane) & 1u) {
+            r = L[P_H12 + lane];
+            for (int c = 0; c < 12; c++) if ((live >> c) & 1u) r -= L[F_M + 12 * lane + c] * L[F_PT + 25 * c + 12];
+        }
+        L[F_V + 12 + lane] = (double)(float)r;
+    }
+    WSYNC();
+    if (lane < 12) {
+        float dw = 0.0f;
+        for (int c = 0; c < 12; c++) dw = fmaf(ldf(L, F_PT + 25 * lane + 13 + c), ldf(L, F_V + 12 + c), dw);
+        L[F_V + 24 + lane] = ((live >> lane) & 1u) ? (double)(ldf(L, F_PT + 25 * lane + 12) + dw) : 0.0;
+    }
+    WSYNC();
+    return bad;
+}
+
+// fp32 form of cone_pushthrough: K_f = G_F G_F' and its inverse by Gauss-Jordan in fp32 (a pivot below 1e-4 of its diagonal = rank
+// deficient: return 0, the caller takes the fp64 general route), the 12 x 12 solve above, y = K^-1 w, s_j = g_j' y.
+// `fmask_out`: bit f set = foot f carries free coefficients (its multipliers are -eps s_j, accurate to eps * 1e-6 |s|).
+__device__ __forceinline__ int cone_pushthrough_f32(double *L, const LmhDevParams &P, unsigned F, double *s_out, int *flags)
+{
+    const int lane = LANE;
+    const unsigned FR = F & 0xFFFFu, FL = F >> 16;
+    const bool useR = FR != 0u, useL = FL != 0u;
+    const float eps = (float)P.eps_coeff;
+    WSYNC();
+    for (int e = lane; e < 144; e += 64) {                         // [K_f | I]
+        const int ft = e / 72, a = (e % 72) / 12, c = e % 12;
+        float v;
+        if (c < 6) {
+            v = 0.0f;
+            for (unsigned m = ft ? FL : FR; m; m &= m - 1u) { const int j = __builtin_ctz(m); v = fmaf(ldf(L, P_GCOL + 6 * j + a), ldf(L, P_GCOL + 6 * j + c), v); }
+        } else v = (c - 6 == a) ? 1.0f : 0.0f;
+        L[F_K + e] = (double)v;
+    }
+    int sing = 0;
+    if (useR) sing |= gj_lds_f32(L + F_K, 6, 6, 12, 0x3Fu, 1e-4f);
+    if (useL) sing |= gj_lds_f32(L + F_K + 72, 6, 6, 12, 0x3Fu, 1e-4f);
+    if (sing) return 0;
+    for (int e = lane; e < 72; e += 64) {
+        const int ft = e / 36, a = (e % 36) / 6, c = e % 6;
+        const bool used = ft ? useL : useR;
+        L[F_KI + e] = used ? (double)(0.5f * (ldf(L, F_K + 72 * ft + 12 * a + 6 + c) + ldf(L, F_K + 72 * ft + 12 * c + 6 + a))) : 0.0;
+    }
+    const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
+    if (pushthrough_solve_f32(L, L + F_KI, eps, live)) *flags |= LMH_FLAG_NOT_SPD;
+    if (lane < 12) {
+        const int fi = lane / 6, ri = lane % 6;
+        const bool used = (fi == 0) ? useR : useL;
+        float yv;
+        if (used) {
+            yv = 0.0f;
+            for (int k = 0; k < 6; k++) yv = fmaf(ldf(L, F_KI + 36 * fi + 6 * ri + k), ldf(L, F_V + 24 + 6 * fi + k), yv);
+        } else {                                                   // foot without force: -(W w - h) / eps (the multipliers come out as g_j'(W w - h))
+            double rv = -L[P_H12 + lane];
+            for (int k = 0; k < 12; k++) rv += L[P_W + 12 * lane + k] * L[F_V + 24 + k];
+            yv = -(float)rv / eps;
+        }
+        L[F_V + 36 + lane] = (double)yv;
+    }
+    WSYNC();
+    float sj = 0.0f;
+    if (lane < 32) {
+        for (int k = 0; k < 6; k++) sj = fmaf(ldf(L, P_GCOL + 6 * (lane & 15) + k), ldf(L, F_V + 36 + 6 * (lane >> 4) + k), sj);
+    }
+    *s_out = (double)sj;
+    return 1;
+}
+
 // min 1/2 c'Pc - qv'c  s.t. c >= 0, c_j = 0 for j in `forced`.  P = G'WG + eps I is SPD, so the
 // minimiser is unique.  Fast path: block principal pivoting from the incoming free set (one solve when
 // the active set did not change, typically <= 8 from a cold start).  If that has not settled after
 // BPP_MAX rounds, a Lawson-Hanson active-set pass from the empty set finishes (monotone, finite).
 // One loop, one call site of the (large, fully unrolled) free-set solve.
 // P.bpp_max (lmh_config.bpp_rounds): 10 by default; < 0 skips block pivoting altogether (diagnostic: Lawson-Hanson from the empty set)
+template <bool F32 = false>
 __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters, double *dbgp = nullptr)
 {
+    constexpr double TOLC = F32 ? 1e-5 : 1e-10;                   // primal sign test, relative to max |c| (fp32: ~100 ulp of the push-through solve)
     const int lane = LANE;
     int flags = 0, it = 0;
     forced = (unsigned)__builtin_amdgcn_readfirstlane((int)forced);
@@ -1829,6 +2070,17 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         // (W + eps (G G')^-1) w = h and c = G'(G G')^-1 w  (push-through identity; G G' is constant,
         // block diagonal and well conditioned) -- 12 pivots instead of 32.
         it++;
+        double zj = 0.0;
+        if constexpr (F32) {
+            WSYNC();
+            for (int e = lane; e < 72; e += 64) L[F_KI + e] = L[P_GI6 + e % 36];
+            if (pushthrough_solve_f32(L, L + F_KI, (float)P.eps_coeff, 0xFFFu)) flags |= LMH_FLAG_NOT_SPD;
+            if (lane < 32) {
+                float z = 0.0f;
+                for (int k = 0; k < 6; k++) z = fmaf(ldf(L, P_GPI + 6 * (lane & 15) + k), ldf(L, F_V + 24 + 6 * (lane >> 4) + k), z);
+                zj = (double)z;
+            }
+        } else {
 #ifndef LMH_LDL_AF
         double a[12], b[1];
         {
@@ -1864,15 +2116,15 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         WSYNC();
         if (lane < 12) L[P_U12 + lane] = b[0];
         WSYNC();
-        double zj = 0.0;
         if (lane < 32) {
             const double *gp = L + P_GPI + 6 * (lane & 15), *u = L + P_U12 + 6 * (lane >> 4);
 #pragma unroll
             for (int k = 0; k < 6; k++) zj += gp[k] * u[k];
         }
+        }
         WSTAMP(34);
         const double cmax = wave_max(fabs(zj));
-        const unsigned bad = (unsigned)__ballot(lane < 32 && zj < -1e-10 * (1.0 + cmax));
+        const unsigned bad = (unsigned)__ballot(lane < 32 && zj < -TOLC * (1.0 + cmax));
         WSTAMP(35);
         cj = zj;
         if (bad == 0u) {
@@ -1893,12 +2145,24 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         double zj;
         if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
         double sj;
-        const int have_ki = __builtin_amdgcn_readfirstlane((F == (unsigned)L[P_KF + 1]) ? (int)L[P_KF + 2] : 0);   // prepared by the helper wave for the warm-start set
-        if (!lh && cone_pushthrough(L, P, F, have_ki, &sj, &flags)) {   // 12 x 12 route: coefficients and multipliers from one vector
+        const int have_ki = F32 ? 0 : __builtin_amdgcn_readfirstlane((F == (unsigned)L[P_KF + 1]) ? (int)L[P_KF + 2] : 0);   // prepared by the helper wave for the warm-start set
+        double tolm = toll;                                        // dual sign test of this round
+        bool pt;
+        if constexpr (F32) pt = !lh && cone_pushthrough_f32(L, P, F, &sj, &flags);
+        else pt = !lh && cone_pushthrough(L, P, F, have_ki, &sj, &flags);
+        if (pt) {                                                  // 12 x 12 route: coefficients and multipliers from one vector
             const bool fr = (lane < 32) && ((F >> lane) & 1u);
             zj = fr ? sj : 0.0;
             lj = (lane < 32 && !fr) ? -P.eps_coeff * sj : 0.0;
+            if constexpr (F32) {
+                // fp32 multipliers: -eps s_j on a foot with free coefficients (good to eps * 1e-6 |s|); on a foot without, g_j'(W w - h), a
+                // difference of O(|h|) terms (good to 1e-6 |q|)
+                const double smax = wave_max((lane < 32) ? fabs(sj) : 0.0);
+                const bool footfree = ((lane & 16) ? (F >> 16) : (F & 0xFFFFu)) != 0u;
+                tolm = footfree ? 2e-5 * P.eps_coeff * (1.0 + smax) : 2e-5 * (1.0 + qmax);
+            }
         } else {
+            if constexpr (F32) flags |= LMH_FLAG_QP_FP64_ROUTE;    // rank-deficient contact set (or the Lawson-Hanson pass): fp64 general route
 #ifdef LMH_OLD_P
             if (!have_p) { build_cone_matrix(L, P); have_p = true; }
 #else
@@ -1910,8 +2174,8 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         const bool inF = (lane < 32) && ((F >> lane) & 1u);
         if (!lh) {
             const double cmax = wave_max(fabs(zj));
-            const double tolc = 1e-10 * (1.0 + cmax);
-            const bool isbad = mine && ((inF && zj < -tolc) || (!inF && lj < -toll));
+            const double tolc = TOLC * (1.0 + cmax);
+            const bool isbad = mine && ((inF && zj < -tolc) || (!inF && lj < -tolm));
             const unsigned bad = (unsigned)__ballot(isbad);
             if (dbgp && lane == 0 && it <= 12) { dbgp[3960 + it] = (double)F; dbgp[3975 + it] = (double)bad; }   // round trace (diagnostics)
             cj = zj;
@@ -2295,7 +2559,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
         if constexpr (false) {
 #else
         if constexpr (NU <= 16) {                                  // Gauss-Jordan on full rows
-#endif (B_CF is the full symmetric copy): no masked loads
+#endif                                                             // (B_CF is the full symmetric copy): no masked loads
             const int lr = on ? lane : 0;
 #pragma unroll
             for (int c = 0; c < NU; c++) a[c] = L[B_CF + 18 * lr + c];
@@ -2410,15 +2674,21 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
 }
 
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
-template <int NW>
+template <int NW, bool F32 = false>
 __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
 {
     const int lane = LANE;
-    int flags = (P.w_com_ang == 0.0) ? qp_setup15<NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
+    int flags;
+    if constexpr (F32) {
+        if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
+        flags = qp_setup_f32(L, P);
+    } else {
+    flags = (P.w_com_ang == 0.0) ? qp_setup15<NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
     WSTAMP(18);
     bsync<NW>();                                                   // Y (helper wave) is complete; the cone solve may overwrite the set-up scratch
     if (NW == 2 && wid != 0) { WSTAMP(26); bsync<NW>(); WSTAMP(27); return 0; }            // the active-set iteration and the recovery are sequential: wave 0;
                                                                    // the helper waits for the free set it will prepare K^-1 for
+    }
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
     // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
     unsigned forced = 0u;
@@ -2427,13 +2697,42 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     unsigned F = (P.warm_start ? *Fmask_io : 0xFFFFFFFFu) & ~forced;
     int it = 0;
     WSTAMP(24);
-    flags |= cone_qp(L, P, forced, &F, &it, dbgp);
+    flags |= cone_qp<F32>(L, P, forced, &F, &it, dbgp);
     WSYNC();
     WSTAMP(25);
     *Fmask_io = F;
     *iters_out = it;
     if (lane == 0) L[P_KF] = (double)F;                            // published for the helper wave (next evaluation's warm start)
     if (dbgp && LANE == 0) dbgp[4013] = (double)clock64();
+    if constexpr (F32) {                                           // the recovery below in fp32
+        if (lane < 12) {
+            const int ft = lane / 6, k = lane % 6;
+            float sacc = 0.0f;
+            for (int j = 0; j < 16; j++) sacc = fmaf(ldf(L, P_GCOL + 6 * j + k), ldf(L, P_CC + 16 * ft + j), sacc);
+            L[P_W12 + lane] = (double)sacc;
+        }
+        WSYNC();
+        if (lane < 6) {
+            float sacc = 0.0f;
+            for (int row = 0; row < 12; row++) sacc = fmaf((float)jdense(L, row, lane), ldf(L, P_W12 + row), sacc);
+            L[F_V + lane] = (double)(sacc - ldf(L, P_D6 + lane));
+        }
+        WSYNC();
+        if (lane < 6) {
+            float lam = 0.0f;
+            for (int k = 0; k < 6; k++) lam = fmaf(ldf(L, P_SI + 6 * lane + k), ldf(L, F_V + k), lam);
+            L[P_LAM6 + lane] = (double)(-lam);
+        }
+        WSYNC();
+        if (lane < 30) {
+            float sacc = ldf(L, P_YT + lane);
+            for (int k = 0; k < 6; k++) sacc = fmaf(ldf(L, P_YT + 30 * (1 + k) + lane), ldf(L, P_LAM6 + k), sacc);
+            L[P_A + lane] = (double)(-sacc);
+        }
+        WSYNC();
+        bsync<NW>();
+        return flags;
+    }
     // ---- recover w = G c, lam = -Si (Jb' w - d), a = -(Y_g + Y_M lam)
     if (lane < 12) {
         const int ft = lane / 6, k = lane % 6;
@@ -2632,7 +2931,7 @@ __device__ __forceinline__ void phase_outputs_qdd(double *L, int a_src = P_A)
 // call this with their wave index; every bsync below is reached by both (uniform control flow), all other fences
 // are wave-local.  Wave 1 never touches P_Q / P_V / the QP scratch after its last bsync, so wave 0 may run ahead
 // into the next evaluation's forward kinematics.
-template <int NW, typename R>
+template <int NW, typename R, bool QF32 = false>
 __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
 {
     int flags = 0, ph = 0;
@@ -2695,7 +2994,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     bsync<NW>();
     WSTAMP(8);
     STAMP(7);
-    flags |= phase_qp<NW>(L, P, ph, wid, Fmask, iters_out, dbg);
+    flags |= phase_qp<NW, QF32>(L, P, ph, wid, Fmask, iters_out, dbg);
     STAMP(8);
     const bool plant = P.plant != 0;                               // wave-uniform
     if (plant && (NW == 1 || wid == 0)) phase_plant(L, P);         // the torques drive a plant instead of being thrown away (main.cpp:118-121)
@@ -2782,7 +3081,7 @@ __device__ __forceinline__ void store_out(const double *L, double *out)
 // Controller::standStep + WBC for every instance (src/controller.cpp:48-154).
 // The plain kernel runs two waves per robot like the rollout; the debug kernel (intermediate dumps, stamps) keeps
 // the single-wave schedule.
-template <bool DEBUG, typename R, int NW = (DEBUG ? 1 : 2)>
+template <bool DEBUG, typename R, int NW = (DEBUG ? 1 : 2), bool QF32 = false>
 __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
 {
     __shared__ double L[LDS_DOUBLES];
@@ -2804,7 +3103,7 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, doubl
     bsync<NW>();
     if constexpr (NW == 2) { if (wid == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }   // see lmh_rollout_kernel
     int k = 0, iters = 0;
-    const int flags = controller_eval<NW, R>(L, P, inst, t, wid, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    const int flags = controller_eval<NW, R, QF32>(L, P, inst, t, wid, &F, &k, &iters, DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
     bsync<NW>();                                                   // torques of the helper wave
     if (wid == 0) {
         store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
@@ -2820,7 +3119,7 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, doubl
 // Workgroup = LMH_ROLLOUT_THREADS = 2 waves per robot (see bsync): 4 robots = 8 waves per CU, two per SIMD, so the
 // kernel is held to 256 registers.  Wave 0 owns the RK4 state (lane i < 60 <-> component i) and everything
 // sequential; wave 1 joins for the phases controller_eval<2> splits.
-template <typename R>
+template <typename R, bool QF32 = false>
 #ifndef LMH_ROLLOUT_ATTR
 #define LMH_ROLLOUT_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
@@ -2878,7 +3177,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, 
 #ifndef LMH_PARAM_BYVAL
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
 #endif
-            flags |= controller_eval<2, R>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr);
+            flags |= controller_eval<2, R, QF32>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
                 // xdot (apps/offline/main.cpp:107-121)
@@ -3325,14 +3624,17 @@ extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *ou
     // LMH_DIAG_NW2=1: the debug kernel on the two-wave schedule (per-wave phase stamps; diagnostics only)
     static const bool diag_nw2 = getenv("LMH_DIAG_NW2") != nullptr;     // read once
     if (debug && diag_nw2) hipLaunchKernelGGL((lmh_eval_kernel<true, double, 2>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
+    else if (debug && P->precision == 2) hipLaunchKernelGGL((lmh_eval_kernel<true, float, 1, true>), dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
     else if (debug) hipLaunchKernelGGL((lmh_eval_kernel<true, double>), dim3(P->n_instances), dim3(64), 0, s, *P, state, out, status, debug);
+    else if (P->precision == 2) hipLaunchKernelGGL((lmh_eval_kernel<false, float, 2, true>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
     else if (P->precision == 1) hipLaunchKernelGGL((lmh_eval_kernel<false, float>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
     else hipLaunchKernelGGL((lmh_eval_kernel<false, double>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
 }
 // d_P: device copy of *P (the rollout kernel reads its parameters through a pointer, see lmh_rollout_kernel)
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
 {
-    if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
+    if (P->precision == 2) hipLaunchKernelGGL((lmh_rollout_kernel<float, true>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
+    else if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
     else hipLaunchKernelGGL(lmh_rollout_kernel<double>, dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
 }
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s)

@@ -515,3 +515,72 @@ def test_bench_default_line_shape():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["cpu_model"]
     assert cb["parity_vs_gpu_last_tick_max_rel"] < 1e-6
     assert cb["literal_2wbc_value"] and cb["literal_2wbc_value"] < cb["value"] * 1.05
+
+
+# ------------------------------------------------------------------------------- BASELINE config 5: fp32-vs-fp64 tolerance sweep
+def test_config5_precision_sweep_pass_rates():
+    """north_star's "fp32 vs fp64 tolerance sweep" on SURVEY 8d's schedule (0.4 s stance, 0.15 s flight, landing; N = 48): the sweep of
+    scripts/precision_sweep.py on 256 robots (profiles/r02_precision_sweep.json holds the 1024-robot table).  LMH_PRECISION_MIXED = fp32
+    model terms; LMH_PRECISION_FP32 = the QP too (push-through contact solves with one fp64 residual refinement, fp64 fall-back route for
+    rank-deficient contact sets).  What must hold in every mode: the preview index bit-identical, flight forces exactly zero, no failure
+    flag.  The pass rates asserted are what the arithmetic delivers (measured, then fixed with a margin), not the 1e-6 fp64 parity bar:
+    fp32 holds 1e-2 (tau) / 1e-3 (f) through the stance phase and does NOT hold 1e-2 for every robot at the landing -- the sweep records it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("precision_sweep", os.path.join(ROOT, "scripts", "precision_sweep.py"))
+    ps = importlib.util.module_from_spec(spec); spec.loader.exec_module(ps)
+    r = ps.sweep(B=256, nt=600)
+    assert r["k_bit_identical"] and r["flight_forces_exactly_zero"]
+    assert r["instances_flagged"] == {"fp64": 0, "mixed": 0, "fp32": 0}
+    mx, f32 = r["mixed"], r["fp32"]
+    assert mx["evaluation"]["tau"]["pass_rate"]["0.0001"] >= 0.99 and mx["evaluation"]["f"]["pass_rate"]["0.0001"] >= 0.99
+    assert mx["closed_loop_stance_only"]["tau"]["pass_rate"]["0.0001"] >= 0.999
+    assert f32["evaluation_stance_only"]["tau"]["pass_rate"]["0.01"] >= 0.99 and f32["evaluation_stance_only"]["f"]["pass_rate"]["0.001"] >= 0.99
+    assert f32["closed_loop_stance_only"]["tau"]["pass_rate"]["0.01"] >= 0.99 and f32["closed_loop_stance_only"]["f"]["pass_rate"]["0.001"] >= 0.99
+    assert f32["evaluation"]["tau"]["p50"] < 5e-3 and f32["evaluation"]["tau"]["p50"] > 1e-5      # it IS fp32 arithmetic, not the fp64 path
+    # the stance phase never needs the fp64 route (all 32 generators free, or full-rank subsets); the landing does
+    pc = r["fp32_chunks_with_fp64_route"]["per_chunk"]
+    assert max(pc[:40]) == 0.0
+
+
+@pytest.mark.parametrize("over", [dict(), dict(w_com_ang=50.0, mu=0.5)])
+def test_fp32_mode_single_evaluations_against_fp64(cfg2, over):
+    """LMH_PRECISION_FP32 on single evaluations in double support, both single supports and flight, default weights and the 18-row
+    set-up (angular-momentum weight set): against the fp64 path on the same states -- torques within 5e-2 / forces within 5e-3 of
+    the vector scale for >= 95 % of the robots (measured: tau p50 3e-3..5e-3, p95 1.6e-2; f p50 6e-4, p95 1.5e-3 -- the error is the
+    fp32 Woodbury / Schur set-up's, the flight phase without any contact solve shows the same 2e-3), the active-set iteration takes the
+    same number of rounds as in fp64, forces of a foot out of support exactly zero, friction cones hold to fp32 round-off, no failure
+    flag; and the result differs from fp64 (it is not the fp64 path)."""
+    from linearmpchumanoid_amd import capi
+    B = 256
+    v = perturbed_velocities(B, seed=77) * 0.2
+    vprev = v - perturbed_velocities(B, seed=78) * 0.004
+    mu = over.get("mu", 0.7)
+    hard = capi.FLAG_QP_MAXITER | capi.FLAG_NONFINITE | capi.FLAG_ZMP_RANGE | capi.FLAG_NOT_SPD
+    for ph in (0, 1, 2, 3):
+        res = {}
+        for prec in (capi.PRECISION_FP64, capi.PRECISION_FP32):
+            ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=0, precision=prec, **over)
+            n = 2500
+            ctl.set_refs(np.zeros(n), np.zeros(n), np.full(n, ph, dtype=np.uint8))
+            st = ctl.new_state(cfg2["q0"], v, t=0.0, v_prev=vprev)
+            out, status = ctl.stand_step(st)[:2]
+            torch.cuda.synchronize()
+            res[prec] = (out.cpu().numpy(), status.cpu().numpy())
+        o64, s64 = res[capi.PRECISION_FP64]
+        o32, s32 = res[capi.PRECISION_FP32]
+        assert ((s32[:, 2] & hard) == 0).all() and (s64[:, 2] == 0).all() and np.array_equal(s32[:, 0], s64[:, 0])
+        e_tau = np.abs(o32[:, :24] - o64[:, :24]).max(axis=1) / np.abs(o64[:, :24]).max(axis=1)
+        assert (e_tau <= 5e-2).mean() >= 0.95 and 1e-6 < np.median(e_tau) < 1e-2, (ph, np.median(e_tau), e_tau.max())
+        assert np.abs(s32[:, 1] - s64[:, 1]).max() <= 2           # same active-set path (a round more or less at a degenerate vertex)
+        f64_, f32_ = o64[:, 24:36], o32[:, 24:36]
+        if ph == 3:
+            assert np.abs(f32_).max() == 0.0
+            continue
+        e_f = np.abs(f32_ - f64_).max(axis=1) / np.abs(f64_).max(axis=1)
+        assert (e_f <= 5e-3).mean() >= 0.95, (ph, np.median(e_f), e_f.max())
+        if ph == 1: assert np.abs(f32_[:, 6:]).max() == 0.0        # left foot out of support
+        if ph == 2: assert np.abs(f32_[:, :6]).max() == 0.0
+        for ft in range(2):
+            fx, fy, fz = f32_[:, 6 * ft + 3], f32_[:, 6 * ft + 4], f32_[:, 6 * ft + 5]
+            sc = 1e-4 * (1.0 + np.abs(f32_).max(axis=1))
+            assert (fz > -sc).all() and (np.abs(fx) <= mu * fz + sc).all() and (np.abs(fy) <= mu * fz + sc).all()
