@@ -49,7 +49,7 @@ def make_summary(state, out, status, ctl=None):
 
 def gather_summaries(summary, world, rank, dst=0):
     """Gather per-rank [B_r,16] summaries on `dst` in instance order; returns None elsewhere."""
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return summary
     n_local = torch.tensor([summary.shape[0]], dtype=torch.int64, device=summary.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]

@@ -584,3 +584,32 @@ def test_fp32_mode_single_evaluations_against_fp64(cfg2, over):
             fx, fy, fz = f32_[:, 6 * ft + 3], f32_[:, 6 * ft + 4], f32_[:, 6 * ft + 5]
             sc = 1e-4 * (1.0 + np.abs(f32_).max(axis=1))
             assert (fz > -sc).all() and (np.abs(fx) <= mu * fz + sc).all() and (np.abs(fy) <= mu * fz + sc).all()
+
+
+def test_rccl_collectives_of_the_bench_on_device_tensors(cfg2):
+    """The collectives bench.py issues with --backend nccl (RCCL): barrier, all_gather of the [B,16] summaries (device tensors, straight
+    from lmh_make_summary), MAX / SUM all_reduce -- on a one-rank RCCL group, which is all a one-GPU box can form (two ranks on one
+    card are refused by RCCL; the two-rank path runs over gloo in test_bench_two_ranks_through_the_gpus_flag)."""
+    import torch.distributed as dist
+    from linearmpchumanoid_amd import sharding
+    B = 64
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=1)
+    ctl.set_refs_stance(1.0, 2)
+    st = ctl.new_state(cfg2["q0"], perturbed_velocities(B), t=0.0)
+    out, status, _ = ctl.rollout(st, 5)
+    summary = sharding.make_summary(st, out, status, ctl)
+    assert summary.is_cuda
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    try:
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+        g = sharding.gather_summaries(summary, 1, 0)
+        assert g.is_cuda and g.shape == (B, 16) and torch.equal(g, summary)
+        tt = torch.tensor([1.25], dtype=torch.float64, device=summary.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ft = torch.tensor([3], dtype=torch.int64, device=summary.device)
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert float(tt.item()) == 1.25 and int(ft.item()) == 3
+    finally:
+        dist.destroy_process_group()
