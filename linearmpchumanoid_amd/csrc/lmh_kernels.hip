@@ -668,9 +668,6 @@ __device__ __forceinline__ v4d mfma_tile(FA a_of, FB b_of)
 // the library routine with its large-argument path.  Accurate to ~1 ulp (a host libm is ~0.5 ulp; the difference is 1e-16).
 __device__ __forceinline__ void sincos_r(double x, double *s, double *c)
 {
-#ifdef LMH_LIBM_SINCOS
-    sincos(x, s, c);
-#else
     const double n = rint(x * 6.36619772367581382433e-01);        // 2 / pi
     double r = fma(-n, 1.57079632673412561417e+00, x);             // pio2 to 33 bits: n * pio2_1 is exact
     r = fma(-n, 6.07710050650619224932e-11, r);
@@ -685,7 +682,6 @@ __device__ __forceinline__ void sincos_r(double x, double *s, double *c)
     const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
     *s = (q & 2) ? -ss : ss;
     *c = ((q + 1) & 2) ? -cc : cc;
-#endif
 }
 __device__ __forceinline__ void sincos_r(float x, float *s, float *c) { sincosf(x, s, c); }
 
@@ -1040,7 +1036,7 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
         const R hi[3] = {cb ? ic[0] : p0, cb ? ic[1] : p1, cb ? ic[2] : p2};
         WSYNC();                                                   // A_YT of the previous level has been consumed
         {
-            const LV<R> E = L + A_XE + 9 * i, Bm = L + A_XB + 9 * i;
+            const LV<R> E = L + A_XE + 9 * i;
             const R l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
             // second operand: row c of E (cb = 1) or column c of B (cb = 0) -- selected by ADDRESS (base, stride), three loads
             const LV<R> Xs = L + (cb ? A_XE : A_XB) + 9 * i;
@@ -1276,7 +1272,13 @@ __device__ __forceinline__ void refs_ag(double *L, double mass)
         }
         L[P_AG + e] = val;
     }
-    if (lane < 6) {                                                // AGpqp = X1G Cg[0:6]
+}
+// AGpqp = X1G Cg[0:6] (Dynamics.cpp:103-121): needs the mass matrix (CRBA) AND the gravity-free bias (Newton-Euler); on the two-wave
+// schedule those come from different waves, so this piece runs after their join (phase_qp), not inside the reference chains
+__device__ __forceinline__ void refs_agpqp(double *L, double mass)
+{
+    const int lane = LANE;
+    if (lane < 6) {
         const double *T0 = L + P_TB, *cg = L + P_CG;
         const int r = lane % 3;
         double val;
@@ -1397,6 +1399,7 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
     if (pre.k < 0 || pre.k + P.horizon >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;    // on every wave (wave 0 reports)
     if constexpr (NW == 1) {
         refs_ag(L, mass);
+        refs_agpqp(L, mass);
         WSYNC();
         SUBSTAMP(12);
         refs_momentum(L, mass);
@@ -1596,18 +1599,6 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double eps,
     if (lane < 32) L[P_CC + lane] = zj;
     WSYNC();
     double s = 0.0;
-#ifdef LMH_OLD_P
-    {
-        const double *Pr = L + C_P + 33 * r + 16 * half, *cc = L + P_CC + 16 * half;
-#pragma unroll
-        for (int bq = 0; bq < 16; bq++) s += Pr[bq] * cc[bq];
-    }
-    {   // s[l] + s[l ^ 32] in every lane: gfx950 v_permlane32_swap (no LDS round trip)
-        const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(s), __double2loint(s), false, false);
-        const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(s), __double2hiint(s), false, false);
-        s = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
-    }
-#else
     {   // (P z)_r = g_r' W (G z) + eps z_r through the wrench G z: three short LDS steps instead of a 32 x 32 image of P
         (void)half;
         double *wz = L + C_LS, *Wwz = L + C_LS + 16;               // the rows of L parked by the solve above are dead
@@ -1631,7 +1622,6 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double eps,
 #pragma unroll
         for (int k = 0; k < 6; k++) s += g[k] * y[k];
     }
-#endif
     *z_out = zj;
     *lam_out = (lane < 32 && !((F >> lane) & 1u)) ? s - L[P_QV + r] : 0.0;
     return bad;
@@ -1648,32 +1638,6 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double eps,
 // per DPP row) and a 12 x 12 solve replace the |F| x |F| factorisation.  A foot without any free coefficient
 // carries no force (its rows are dropped).  Returns 0 (wave-uniform) when some K_f is numerically singular: the
 // caller then takes the general P_FF solve.
-template <int J>
-__device__ __forceinline__ void ldl6_pair_step(double (&a)[6], double (&b)[6], int l16, bool rowon, int &bad, double &myinv)
-{
-    if constexpr (J < 6) {
-        double d = bcast16<J>(a[J]);                               // lane J of each DPP row: that foot's pivot
-        if (rowon && !(d > 1e-12)) bad = 1;                        // K_f entries are O(1e-3 .. 10); a rank-deficient block pivots at ~1e-17
-        d = (rowon && d > 1e-12) ? d : 1.0;
-        const double invd = fast_rcp(d);
-        const double f = a[J] * invd;
-        const double nfm = (l16 > J) ? -f : 0.0;
-        if (l16 == J) myinv = invd;
-        dpp_fmac_tail<J + 1>(a, a[J], -f);
-        dpp_fmac_rhs<J>(b, nfm);
-        if (l16 > J) a[J] = f;
-        ldl6_pair_step<J + 1>(a, b, l16, rowon, bad, myinv);
-    }
-}
-template <int J>
-__device__ __forceinline__ void ldl6_pair_back(double (&b)[6], int l16, const double *Lrow)
-{
-    if constexpr (J > 0) {
-        const double nl = (l16 < J) ? -Lrow[7 * J + ((l16 < 6) ? l16 : 0)] : 0.0;
-        dpp_fmac_rhs<J>(b, nl);
-        ldl6_pair_back<J - 1>(b, l16, Lrow);
-    }
-}
 // K_f^-1 of both feet for the free set F into Kdst (2 x 36); `scr` = 160 doubles of scratch.  Returns non-zero
 // (wave-uniform) when a foot with free coefficients has a singular K_f.
 __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst, double *scr)
@@ -1681,8 +1645,7 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
     const int lane = LANE, l16 = lane & 15, row = lane >> 4;
     const unsigned FR = F & 0xFFFFu, FL = F >> 16;
     const bool useR = FR != 0u, useL = FL != 0u;
-    double *K = scr, *Ki = Kdst, *Ls = scr + 72;
-    (void)Ls;
+    double *K = scr, *Ki = Kdst;
     WSYNC();
     {   // K_f = G diag(free_f) G' for both feet as ONE 16 x 16 x 16 matrix-core product: row block f of A carries foot f's
         // mask, so the two diagonal 6 x 6 blocks of the tile are K_R and K_L (the off-diagonal blocks are not used)
@@ -1704,7 +1667,6 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
         const bool rowon = (row == 0 && useR) || (row == 1 && useL);
         const bool on = rowon && l16 < 6;
         const int rb = (row < 2) ? 36 * row : 0, lr = (l16 < 6) ? l16 : 0;
-#ifndef LMH_LDL_KINV
         double a[6], bb[6], myinv = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; c++) { a[c] = K[rb + 6 * lr + c]; bb[c] = (l16 == c) ? 1.0 : 0.0; }      // full rows (Gauss-Jordan), both feet at once
@@ -1713,22 +1675,6 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
 #pragma unroll
         for (int c = 0; c < 6; c++) bb[c] *= myinv;
         if (row < 2 && l16 < 6) {
-#else
-        double a[6], bb[6], myinv = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) { a[c] = (on && c <= l16) ? K[rb + 6 * lr + c] : 0.0; bb[c] = (on && l16 == c) ? 1.0 : 0.0; }
-        ldl6_pair_step<0>(a, bb, l16, rowon, bad, myinv);
-#pragma unroll
-        for (int c = 0; c < 6; c++) bb[c] *= myinv;
-        WSYNC();
-        if (row < 2 && l16 < 6) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) Ls[42 * row + 7 * l16 + c] = a[c];
-        }
-        WSYNC();
-        ldl6_pair_back<5>(bb, l16, Ls + ((row < 2) ? 42 * row : 0));
-        if (row < 2 && l16 < 6) {
-#endif
 #pragma unroll
             for (int c = 0; c < 6; c++) Ki[36 * row + 6 * l16 + c] = on ? bb[c] : 0.0;       // K_f^-1 (symmetric); 0 for a foot without force
         }
@@ -1743,12 +1689,11 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
     const int lane = LANE;
     const unsigned FR = F & 0xFFFFu, FL = F >> 16;
     const bool useR = FR != 0u, useL = FL != 0u;
-    double *Ki = (have_ki == 1) ? L + P_KI : L + C_LS + 72, *Yv = L + C_LS + 144, *Ls = L + C_LS + 200;
+    double *Ki = (have_ki == 1) ? L + P_KI : L + C_LS + 72, *Yv = L + C_LS + 144;
     if (have_ki == 2) return 0;
     if (have_ki == 0 && kinv_compute(L, F, L + C_LS + 72, L + C_LS + 240)) return 0;     // wave-uniform: some K_f is singular
     WSYNC();
     {   // (W + eps K^-1) w = h on the rows of the feet that carry force
-#ifndef LMH_LDL_PT
         double a[12], b[1];
         const int lr = (lane < 12) ? lane : 0, fi = lr / 6, ri = lr % 6;
         const bool rowuse = (lane < 12) && ((fi == 0) ? useR : useL);
@@ -1761,24 +1706,6 @@ __device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P
         b[0] = L[P_H12 + lr];
         const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
         if (gj_solve_regs<12, 1>(a, b, live)) *flags |= LMH_FLAG_NOT_SPD;
-#else
-        double a[12], b[1];
-        const int fi = lane / 6, ri = lane % 6;
-        const bool rowuse = (lane < 12) && ((fi == 0) ? useR : useL);
-#pragma unroll
-        for (int c = 0; c < 12; c++) {
-            double v = 0.0;
-            const bool coluse = (c < 6) ? useR : useL;
-            if (rowuse && coluse && c <= lane) {
-                v = L[P_W + 12 * lane + c];
-                if (c / 6 == fi) v += P.eps_coeff * Ki[36 * fi + 6 * ri + c % 6];
-            }
-            a[c] = v;
-        }
-        b[0] = rowuse ? L[P_H12 + lane] : 0.0;
-        const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
-        if (ldl_solve_regs<12, 1>(a, b, live, Ls)) *flags |= LMH_FLAG_NOT_SPD;
-#endif
         WSYNC();
         if (lane < 12) Yv[lane] = rowuse ? b[0] : 0.0;             // w
     }
@@ -2062,8 +1989,7 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
     const int bpp_max = P.bpp_max;
     bool lh = bpp_max < 0;                                         // false: block pivoting, true: Lawson-Hanson
     if (lh) F = 0u;
-    bool have_p = false;                                           // cone Hessian formed (general solve only)
-    if (dbgp) { build_cone_matrix(L, P); have_p = true; }          // the debug record dumps it
+    if (dbgp) build_cone_matrix(L, P);                             // the debug record dumps the 32 x 32 cone Hessian (the solves never form it)
     double cj = 0.0, lj = 0.0;
     if (!lh && forced == 0u && F == 0xFFFFFFFFu) {
         // every coefficient free (the usual balance case): then w = G c solves the 12 x 12 SPD system
@@ -2081,7 +2007,6 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
                 zj = (double)z;
             }
         } else {
-#ifndef LMH_LDL_AF
         double a[12], b[1];
         {
             const int lr = (lane < 12) ? lane : 0, fi = lr / 6, ri = lr % 6;
@@ -2095,23 +2020,6 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         }
         WSTAMP(32);
         if (gj_solve_regs<12, 1>(a, b, 0xFFFu)) flags |= LMH_FLAG_NOT_SPD;
-#else
-        double a[12], b[1];
-        {
-            const int fi = lane / 6, ri = lane % 6;
-#pragma unroll
-            for (int c = 0; c < 12; c++) {
-                double v = 0.0;
-                if (lane < 12 && c <= lane) {
-                    v = L[P_W + 12 * lane + c];
-                    if (c / 6 == fi) v += P.eps_coeff * L[P_GI6 + 6 * ri + c % 6];
-                }
-                a[c] = v;
-            }
-            b[0] = (lane < 12) ? L[P_H12 + lane] : 0.0;
-        }
-        if (ldl_solve_regs<12, 1>(a, b, 0xFFFu, L + C_LS)) flags |= LMH_FLAG_NOT_SPD;
-#endif
         WSTAMP(33);
         WSYNC();
         if (lane < 12) L[P_U12 + lane] = b[0];
@@ -2138,9 +2046,7 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         F ^= bad;
     }
     for (;;) {
-#ifndef LMH_OLD_CAP
         if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }    // no further solve is started once the cap is reached
-#endif
         it++;
         double zj;
         if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
@@ -2163,11 +2069,7 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
             }
         } else {
             if constexpr (F32) flags |= LMH_FLAG_QP_FP64_ROUTE;    // rank-deficient contact set (or the Lawson-Hanson pass): fp64 general route
-#ifdef LMH_OLD_P
-            if (!have_p) { build_cone_matrix(L, P); have_p = true; }
-#else
             build_cone_rows(L, F, P.eps_coeff);                    // P_FF only (the multipliers go through the wrench G z)
-#endif
             if (solve_free_set(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
         }
         if (dbgp && lane == 0 && it <= 12) { dbgp[4021 + 2 * it] = (double)clock64(); dbgp[4050 + it] = (double)__popc(F); }
@@ -2212,9 +2114,6 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
                 F &= ~dm;
             }
         }
-#ifdef LMH_OLD_CAP
-        if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }
-#endif
     }
     WSYNC();
     if (lane < 32) L[P_CC + lane] = ((F >> lane) & 1u) ? cj : 0.0;
@@ -2249,6 +2148,25 @@ __device__ __forceinline__ v4d mfma_ptr(const double *a0, const double *b0)
 //   * S | d = Mb Y = Mb bp' - (Mb D^-1 U') t'' : Z = Mb D^-1 U' and Mb bp' do not depend on the 15 x 15 solve and are formed by the helper
 //     wave while wave 0 solves; the Y tiles (needed only by the recovery) are formed by the helper wave while wave 0 goes on to S^-1, W, h.
 // NW = 2 joins: fills | Cm, q+V | solve, Z+Mbp | (S..qv), Y | -> the caller's join in front of the cone solve.
+// The Jacobian rows of U and U D^-1 (rows 0..11 of the padded operands).  They depend on wave 0's own products only and land in LDS that is
+// dead once its Newton-Euler pass is over (S0 + [0, 408) and S0 + [544, 952): the NE sweeps' scratch and the FK transforms), so on the
+// two-wave schedule wave 0 writes them while wave 1 is still inside CRBA / its reference chain, ahead of the join.
+__device__ __forceinline__ void qp_prefill15(double *L, const LmhDevParams &P)
+{
+    const int lane = LANE;
+    const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int e = lane + 64 * it, r = e >> 5, c = e & 31, o = 34 * r + c;
+        const bool in = c < 30;
+        const double vj = jdense(L, r, in ? c : 0);
+        const double u = in ? vj : 0.0;
+        const double iD = (c < 3) ? idp : (c < 6) ? ida : idj;
+        L[Q_U + o] = u;
+        L[Q_UD + o] = u * iD;
+    }
+}
+
 template <int NW>
 __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int wid, double *dbgp)
 {
@@ -2257,13 +2175,13 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
     constexpr int nU = 15;
     const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
     const int tr = lane & 15, tq = lane >> 4;                      // fragment row / k-quarter; result rows tq + 4 reg, column tr
-    // ---- fills: U, U D^-1 (padded 16 x 32), bp'' (8 x 32), weights
-    for (int e = lane + 64 * wid; e < 512; e += 64 * NW) {
-        const int r = e >> 5, c = e & 31, o = 34 * r + c;
+    // ---- fills: U, U D^-1 (padded 16 x 32; row order: 12 Jacobian rows, 3 linear-momentum rows, one zero row), bp'' (8 x 32), weights
+    if constexpr (NW == 1) qp_prefill15(L, P);                     // NW = 2: wave 0 has already written the Jacobian rows (controller_eval)
+    for (int e = lane; e < ((wid == NW - 1) ? 128 : 0); e += 64) { // rows 12..15: the helper wave (wave 0 forms AGpqp and the weights meanwhile)
+        const int r = 12 + (e >> 5), c = e & 31, o = 34 * r + c;
         const bool in = (r < nU) && (c < 30);
-        const int rs = in ? r : 0, cs = in ? c : 0;
-        const double va = L[P_AG + 30 * (3 + ((rs < 3) ? rs : 0)) + cs], vj = jdense(L, (rs >= 3) ? rs - 3 : 0, cs);
-        const double u = in ? ((rs < 3) ? va : vj) : 0.0;
+        const double va = L[P_AG + 30 * (3 + (in ? r - 12 : 0)) + (in ? c : 0)];
+        const double u = in ? va : 0.0;
         const double iD = (c < 3) ? idp : (c < 6) ? ida : idj;
         L[Q_U + o] = u;
         L[Q_UD + o] = u * iD;
@@ -2276,10 +2194,10 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
         const double vq = -L[P_QREF + is], vm = L[P_MTOP + 30 * ((n > 0) ? n - 1 : 0) + is] * iDi;
         L[Q_BPT + 34 * n + i] = in ? ((n == 0) ? vq : vm) : 0.0;
     }
-    if (wid == NW - 1) {
+    if (wid == 0) {                                                // wave 0: it has just formed AGpqp (phase_qp)
         if (lane < 16) {                                           // Om_r beta_r | 1 / Om_r | beta_r  (row 15: zeros)
             const bool in = lane < nU;
-            const int rr = in ? 3 + lane : 3;                      // row of [AG ; J]
+            const int rr = (lane < 12) ? 6 + lane : in ? 3 + (lane - 12) : 3;      // row of [AG ; J] behind operand row `lane`
             const double om = (rr < 6) ? P.w_com_lin : P.w_foot;
             const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
             L[Q_OB + lane] = in ? om * beta : 0.0;
@@ -2392,7 +2310,6 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
             // (tolerances ~1e-14) do not survive: LDL' on the lower triangle here.
             double a[6], bb[6];
             const int lr = (lane < 6) ? lane : 0;
-#ifndef LMH_LDL_SI
             // Gauss-Jordan on the full S, then S^-1 <- (S^-1 + S^-T) / 2: plain Gauss-Jordan leaves S^-1 (hence W) unsymmetric at the 1e-10 level (it loses
             // ~cond(S) more digits than LDL'), which the active-set tests of the cone QP (tolerances ~1e-14) do not survive; symmetrised, W is symmetric to
             // round-off again and the solve is 1.5k cycles shorter than LDL' with its parked factor (LMH_LDL_SI keeps that form for comparison)
@@ -2407,13 +2324,6 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
                 const double v = 0.5 * (L[Q_LS + 6 * i + j] + L[Q_LS + 6 * j + i]);
                 L[(lane < 36) ? P_SI + e : Q_TRASH + lane] = v;
             }
-#else
-#pragma unroll
-            for (int c = 0; c < 6; c++) { const double sv = L[Q_S + 7 * lr + c]; a[c] = (lane < 6 && c <= lane) ? sv : 0.0; bb[c] = (lane == c) ? 1.0 : 0.0; }
-            if (ldl_solve_regs<6, 6>(a, bb, 0x3Fu, L + Q_LS)) flags |= LMH_FLAG_NOT_SPD;
-#pragma unroll
-            for (int c = 0; c < 6; c++) L[(lane < 6) ? P_SI + 6 * lane + c : Q_TRASH + lane] = bb[c];
-#endif
         }
         WSYNC();
         WSTAMP(20);
@@ -2555,11 +2465,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
     {   // Cm t = V for the 7 right-hand sides, row per lane in registers
         double a[NU], bb[7];
         const bool on = lane < nU;
-#ifdef LMH_LDL_WB
-        if constexpr (false) {
-#else
         if constexpr (NU <= 16) {                                  // Gauss-Jordan on full rows
-#endif                                                             // (B_CF is the full symmetric copy): no masked loads
             const int lr = on ? lane : 0;
 #pragma unroll
             for (int c = 0; c < NU; c++) a[c] = L[B_CF + 18 * lr + c];
@@ -2679,6 +2585,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
 {
     const int lane = LANE;
     int flags;
+    if (NW == 2 && wid == 0) { refs_agpqp(L, L[P_MODEL + 392]); WSYNC(); }     // first point where both M (wave 1) and Cg (wave 0) exist
     if constexpr (F32) {
         if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
         flags = qp_setup_f32(L, P);
@@ -2949,7 +2856,13 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         const unsigned Fpub = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)L[P_KF]);
         const unsigned F0 = (P.warm_start ? Fpub : 0xFFFFFFFFu) & ~forced;
         int st = 0;
-        if (F0 != 0xFFFFFFFFu) st = kinv_compute(L, F0, L + P_KI, L + A_XR) ? 2 : 1;     // all free: the constant table is used instead
+        if (F0 != 0xFFFFFFFFu) {                                   // all free: the constant table is used instead
+            // a foot with 1..5 free generators has K_f = sum of fewer than six rank-one terms: singular without looking (the usual case in
+            // single support, where the sole presses on an edge)
+            const int nR = __popc(F0 & 0xFFFFu), nL = __popc(F0 >> 16);
+            const bool thin = (nR > 0 && nR < 6) || (nL > 0 && nL < 6);
+            st = thin ? 2 : (kinv_compute(L, F0, L + P_KI, L + A_XR) ? 2 : 1);
+        }
         if (LANE == 0) { L[P_KF + 1] = (double)F0; L[P_KF + 2] = (double)st; }
         refs_prepare(L, P, inst, t, pre);
     }
@@ -2986,10 +2899,12 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         STAMP(5);                                                  // per wave: end of its share of the tree phases
     }
     WSTAMP(5);
-    bsync<NW>();
+    // no join here: each wave's reference chain reads only its own tree products (chain A: M; chain B: J, T) and what the com_x join
+    // already published; AGpqp, which needs both, is formed after the next join (phase_qp)
     WSTAMP(6);
     STAMP(6);
     flags |= phase_refs<NW>(L, P, inst, t, pre, wid, k_out, &ph);
+    if (NW == 2 && wid == 0 && P.w_com_ang == 0.0 && !QF32) qp_prefill15(L, P);      // ahead of the join: wave 1's chain is the longer one
     WSTAMP(7);
     bsync<NW>();
     WSTAMP(8);
@@ -3121,17 +3036,18 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, doubl
 // sequential; wave 1 joins for the phases controller_eval<2> splits.
 template <typename R, bool QF32 = false>
 #ifndef LMH_ROLLOUT_ATTR
-#define LMH_ROLLOUT_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef LMH_WAVES_PER_EU
+#define LMH_WAVES_PER_EU 2
+#endif
+#ifdef LMH_NUM_VGPR
+#define LMH_ROLLOUT_ATTR __attribute__((amdgpu_num_vgpr(LMH_NUM_VGPR)))
+#else
+#define LMH_ROLLOUT_ATTR __attribute__((amdgpu_waves_per_eu(LMH_WAVES_PER_EU, LMH_WAVES_PER_EU)))
+#endif
 #endif
 __global__ void __launch_bounds__(LMH_ROLLOUT_THREADS) LMH_ROLLOUT_ATTR
-#ifdef LMH_PARAM_BYVAL
-lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg_unused, LmhDevParams Pv, double *state, double *out, int32_t *status, double *log, int n_ticks)
-{
-    const LmhDevParams *Pg = &Pv;
-#else
 lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, double *state, double *out, int32_t *status, double *log, int n_ticks)
 {
-#endif
     // The parameter block is read through a pointer that is made opaque once per evaluation (params_of): hoisting its ~70 scalars out
     // of the tick loop pins them in SGPRs for the whole launch (round 1: 189 SGPR + 16 VGPR spills, 60 B of scratch per lane that reached
     // HBM); re-reading them costs a few scalar-cache loads per evaluation.
@@ -3174,9 +3090,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, 
                 WSYNC();
             }
             const LmhDevParams *Pe = Pg;
-#ifndef LMH_PARAM_BYVAL
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
-#endif
             flags |= controller_eval<2, R, QF32>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;

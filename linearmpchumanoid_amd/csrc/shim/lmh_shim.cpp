@@ -173,6 +173,7 @@ Controller::Controller(Robot &robot, Mpc3dLip &mpc, ZMP &zmp, std::vector<Eigen:
     int32_t rn[3], ln[3];
     for (int a = 0; a < 3; a++) {
         rn[a] = rFCoeff[static_cast<size_t>(a)].size(); ln[a] = lFCoeff[static_cast<size_t>(a)].size();
+        if (rn[a] > 8 || ln[a] > 8) die("foot polynomial with more than 8 coefficients");      // the staging rows below hold 8
         for (int k = 0; k < rn[a]; k++) r[8 * a + k] = rFCoeff[static_cast<size_t>(a)](k);
         for (int k = 0; k < ln[a]; k++) l[8 * a + k] = lFCoeff[static_cast<size_t>(a)](k);
     }
