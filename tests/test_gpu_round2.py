@@ -613,3 +613,27 @@ def test_rccl_collectives_of_the_bench_on_device_tensors(cfg2):
         assert float(tt.item()) == 1.25 and int(ft.item()) == 3
     finally:
         dist.destroy_process_group()
+
+
+def test_resident_workgroups_cover_every_robot_of_a_ragged_batch(cfg2):
+    """lmh_rollout runs a grid of resident workgroups (4 per CU) that loop over their robots: a batch that is neither below the grid
+    size nor a multiple of it (2500 robots = 2.44 rounds on 256 CUs) must give every robot exactly what it gets in a small batch --
+    bit-identical state, outputs and status for robots of the first, the middle and the ragged last round."""
+    B, nt = 2500, 6
+    v = perturbed_velocities(B, seed=4242)
+    ctl = make_controller(B, cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=1)
+    ctl.set_refs_stance(1.0, 2)
+    st = ctl.new_state(cfg2["q0"], v, t=0.0)
+    out, status, log = ctl.rollout(st, nt, log=True)
+    torch.cuda.synchronize()
+    pick = np.array([0, 1, 511, 1023, 1024, 1025, 2047, 2048, 2300, 2498, 2499])
+    small = make_controller(len(pick), cfg2["dt"], cfg2["th"], cfg2["zcom"], warm_start=1)
+    small.set_refs_stance(1.0, 2)
+    st2 = small.new_state(cfg2["q0"], v[pick], t=0.0)
+    out2, status2, log2 = small.rollout(st2, nt, log=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy()[pick, :91], st2.cpu().numpy()[:, :91])
+    assert np.array_equal(out.cpu().numpy()[pick, :78], out2.cpu().numpy()[:, :78])
+    assert np.array_equal(status.cpu().numpy()[pick], status2.cpu().numpy())
+    assert np.array_equal(log.cpu().numpy()[:, pick], log2.cpu().numpy())
+    assert (status.cpu().numpy()[:, 2] == 0).all() and (status.cpu().numpy()[:, 0] == nt).all()
