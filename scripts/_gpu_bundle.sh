@@ -1,7 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || { tail -20 gpurun_out/smoke.log; exit 1; }
-tail -1 gpurun_out/smoke.log
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu_r02.log 2>&1 || { tail -30 gpurun_out/pytest_gpu_r02.log; exit 1; }
-tail -3 gpurun_out/pytest_gpu_r02.log
+timeout -k 10 600 python -m pytest tests/test_gpu_round2.py -x -q -m gpu -k "torchrun" > gpurun_out/pytest_one.log 2>&1 || { tail -40 gpurun_out/pytest_one.log; exit 1; }
+tail -3 gpurun_out/pytest_one.log

@@ -503,6 +503,28 @@ def test_bench_two_ranks_through_the_gpus_flag(tmp_path):
     assert np.array_equal(s1, s)                                    # sharding does not change any robot's result
 
 
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 2 ...` -- bench.py is then ONE rank per process (no self-launch), reads RANK / LOCAL_RANK / WORLD_SIZE, and rank 0
+    prints the one JSON line.  Both ranks share card 0 over gloo here (a one-GPU box)."""
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["LMH_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--instances", "128",
+           "--steps", "2", "--warmup", "1", "--ticks", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["summary_rows_gathered"] == 256 and res["instances_flagged"] == 0 and res["value"] > 0
+    # a --gpus that disagrees with the launcher's world size is refused, not silently run
+    bad = subprocess.run(cmd[:cmd.index("--gpus") + 1] + ["4"] + cmd[cmd.index("--gpus") + 2:], env=env, capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0
+
+
 def test_bench_default_line_shape():
     """The JSON contract on a reduced workload: config 3 keys, binding roofline first, HBM / MFMA objects beside it, CPU
     baseline on the same workload with the last tick compared against the GPU."""
