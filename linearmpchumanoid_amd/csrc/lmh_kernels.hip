@@ -735,18 +735,31 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
         L[A_T + lane] = val;
     }
     SUBSTAMP(1);
-    const int c = (lane < 60) ? lane / 12 : 4, el = lane % 12, r = el >> 2, col = el & 3;
+    // Chain products T_dst = T_src Lc: every chain is a path (step s reads what step s - 1 wrote), and lane 12 c + 4 r + col holds entry
+    // (r, col) -- the four lanes of a quad are one row of the chain's current transform.  So the recurrence stays in a register and the
+    // row of T_src comes from three quad broadcasts (DPP quad_perm) instead of an LDS store / fence / load per step; the local transforms
+    // do not depend on the recurrence, their loads issue ahead of it.
+    const int c = (lane < 60) ? lane / 12 : 4, el = lane % 12, col = el & 3;
+    WSYNC();
+    R tcur = L[A_T + el];                                          // T0 (every chain starts from the base)
+    R l0[8], l1[8], l2[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {                                  // all 24 operand loads before the first dependent step
+        int dst, src, loc;
+        fk_sched(c, s, &dst, &src, &loc);
+        const LV<R> Lo = L + A_LC + 12 * (((lane < 60) && (dst >= 0)) ? loc : 0) + col;
+        l0[s] = Lo[0]; l1[s] = Lo[4]; l2[s] = Lo[8];
+    }
 #pragma unroll
     for (int s = 0; s < 8; s++) {
-        WSYNC();
         int dst, src, loc;
         fk_sched(c, s, &dst, &src, &loc);
         const bool on = (lane < 60) && (dst >= 0);
-        const LV<R> Ts = L + A_T + 12 * (on ? src : 0) + 4 * r;
-        const LV<R> Lo = L + A_LC + 12 * (on ? loc : 0) + col;
-        R val = Ts[0] * Lo[0] + Ts[1] * Lo[4] + Ts[2] * Lo[8];
-        val += (col == 3) ? Ts[3] : 0.0;
+        const R t0 = dpp_row<0x00>(tcur), t1 = dpp_row<0x55>(tcur), t2 = dpp_row<0xAA>(tcur), t3 = dpp_row<0xFF>(tcur);
+        R val = t0 * l0[s] + t1 * l1[s] + t2 * l2[s];
+        val += (col == 3) ? t3 : 0.0;
         if (on) L[A_T + 12 * dst + el] = val;
+        tcur = on ? val : tcur;
     }
     WSYNC();
 }
@@ -1182,7 +1195,7 @@ __device__ __forceinline__ double jdense(const double *L, int row, int col)
 // (controller.cpp:296-386).
 // Reference samples of one evaluation, fetched from HBM/L2 at the top of controller_eval so that their latency
 // hides behind the kinematics: lane i holds zmp[k + i] (first 64 samples of the preview window).
-struct RefPrefetch { int k; double zx, zy, xs; int ph; };
+struct RefPrefetch { int k; double zx, zy, xs; int ph, seg; };
 __device__ __forceinline__ RefPrefetch prefetch_refs(const LmhDevParams &P, int inst, double t)
 {
     RefPrefetch r;
@@ -1192,7 +1205,9 @@ __device__ __forceinline__ RefPrefetch prefetch_refs(const LmhDevParams &P, int 
     r.zx = P.zmpx[kk]; r.zy = P.zmpy[kk];
     r.xs = P.xscale ? P.xscale[inst] : 1.0;                        // walking extension: per-instance step length
     r.ph = 0;
-    if (P.phase) { const int k0 = (r.k < 0) ? 0 : (r.k >= P.n_samples ? P.n_samples - 1 : r.k); r.ph = P.phase[k0]; }
+    const int k0 = (r.k < 0) ? 0 : (r.k >= P.n_samples ? P.n_samples - 1 : r.k);
+    if (P.phase) r.ph = P.phase[k0];
+    r.seg = (P.n_seg > 0) ? (int)P.seg_of_sample[k0] : 0;          // walking: swing-polynomial segment of sample k (its coefficients are loaded by refs_prepare)
     return r;
 }
 
@@ -1224,8 +1239,7 @@ __device__ __forceinline__ void refs_prepare(double *L, const LmhDevParams &P, i
         int n;
         double tl = t;
         if (P.n_seg > 0) {                                         // walking extension: segment of preview index k
-            const int kk = (k < 0) ? 0 : (k >= P.n_samples ? P.n_samples - 1 : k);
-            const double *sg = P.segs + (size_t)LMH_SEG_STRIDE * P.seg_of_sample[kk];
+            const double *sg = P.segs + (size_t)LMH_SEG_STRIDE * pre.seg;
             const double sc = (ax == 0 && P.xscale) ? P.xscale[inst] : 1.0;
             tl = t - sg[0];
 #pragma unroll
@@ -1372,7 +1386,10 @@ __device__ __forceinline__ void refs_pd_feet(double *L, const LmhDevParams &P, i
         const double cc = fmax(-1.0, fmin(1.0, (tr - 1.0) / 2.0));
         const double phi = acos(cc);
         const double v0 = err[7] - err[5], v1 = err[2] - err[6], v2 = err[3] - err[1];
-        const double sc = (phi < 1e-6) ? 0.5 : (phi / (2.0 * sin(phi)));
+        double sphi, cphi;
+        sincos_r(phi, &sphi, &cphi);                               // phi in [0, pi]: the reduced-range kernel (~1 ulp) instead of the library sin with its large-argument path
+        (void)cphi;
+        const double sc = (phi < 1e-6) ? 0.5 : (phi / (2.0 * sphi));
         const double r0 = sc * v0, r1 = sc * v1, r2 = sc * v2;
         for (int a = 0; a < 3; a++) {
             const double e = -(c_rdes[3 * a] * r0 + c_rdes[3 * a + 1] * r1 + c_rdes[3 * a + 2] * r2);
