@@ -2,7 +2,7 @@
 // (build robot, IK to CoM (-0.02, 0, 0.26), stand for T seconds under RK4 on the controller's own
 // acceleration, print CoM x after every tick), written against the reference's class surface as
 // provided by linearmpchumanoid_amd/csrc/shim.  The reference's own apps/offline/main.cpp compiles
-// against the same headers unchanged (tests/test_shim_build.py does that where /root/reference exists);
+// against the same headers unchanged (tests/test_shim.py does that where /root/reference exists);
 // this file exists because the reference source does not travel to the GPU box.
 // usage: offline_stand [T=5] [dt=0.01] [horizon_s=0.5]
 #include <cstdlib>

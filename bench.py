@@ -74,7 +74,10 @@ def parse(argv=None):
     ap.add_argument("--step-time", type=float, default=0.2, help="walking: time per step (double + single support) [s]")
     ap.add_argument("--ds-time", type=float, default=0.05, help="walking: double-support share of a step [s]")
     ap.add_argument("--settle-time", type=float, default=0.1, help="walking: stance before the first step [s]")
-    ap.add_argument("--precision", type=int, default=0, help="lmh_config.precision (0 fp64, 1 mixed)")
+    ap.add_argument("--precision", type=int, default=0, help="lmh_config.precision (0 fp64, 1 mixed, 2 fp32)")
+    ap.add_argument("--host-io", action="store_true",
+                    help="informational: every step also moves the state host->device and out | status | log device->host through pinned "
+                         "buffers (what a caller holding HOST buffers pays over PCIe); never the default line")
     args = ap.parse_args(argv)
     if args.config is None:
         args.config = 3 if args.gpus == 1 else 4
@@ -373,12 +376,27 @@ def main():
     done = 0
     flags_acc = torch.zeros((), dtype=torch.int32, device=ctl.device)
 
+    host = None
+    if args.host_io:
+        host = dict(state=state.cpu().pin_memory(), out=torch.empty(out.shape, dtype=out.dtype).pin_memory(),
+                    status=torch.empty(status.shape, dtype=status.dtype).pin_memory(),
+                    log=None if log is None else torch.empty(log.shape, dtype=log.dtype).pin_memory())
+
     def step():
         nonlocal done
         if done and done % reset_every == 0:
             state.copy_(state0)                                   # device-to-device, inside the timed region when it happens
             status.zero_()
+            if host is not None:
+                host["state"].copy_(state0, non_blocking=True)
+        if host is not None:
+            state.copy_(host["state"], non_blocking=True)         # the caller's state arrives over PCIe ...
         ctl.rollout(state, args.ticks, out, status, log)
+        if host is not None:                                       # ... and everything the rollout produced goes back
+            host["state"].copy_(state, non_blocking=True); host["out"].copy_(out, non_blocking=True)
+            host["status"].copy_(status, non_blocking=True)
+            if log is not None:
+                host["log"].copy_(log, non_blocking=True)
         done += 1
 
     for _ in range(args.warmup):
@@ -437,7 +455,7 @@ def main():
                        "instances_per_gpu": B, "ticks_per_step": args.ticks, "evaluations_per_tick": 4,
                        "tick_range": [args.warmup * args.ticks, n_launch * args.ticks] if n_launch <= reset_every
                        else f"ticks 0..{reset_every * args.ticks} of every rollout, restarted from the initial states every {reset_every} launches (the closed loop leaves its valid range after that)",
-                       "qp_start": "cold" if args.cold else "warm", "log": log is not None, "parallelism": f"instances sharded x{world}",
+                       "qp_start": "cold" if args.cold else "warm", "log": log is not None, "host_io_over_pcie": bool(args.host_io), "parallelism": f"instances sharded x{world}",
                        "rollout_restarts": (n_launch - 1) // reset_every, "summary_gather_in_timed_region": True},
             "evaluations_per_s": value * 4,
             "roofline": {"bound": "fp64-valu", "achieved": fp64_t, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64_t / FP64_VALU_PEAK_TFLOPS,
