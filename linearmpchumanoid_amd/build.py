@@ -26,7 +26,7 @@ def build(force=False, verbose=False):
     diag += VARIANT.split(":")[1:]
     # iterative-ilp machine scheduler: the kernels run one wave per SIMD, so latency (not register pressure /
     # occupancy) is what the scheduler should optimise; measured +19 % ticks/s over the default strategy.
-    sched = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+    sched = ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("LMH_SCHED", "iterative-ilp")]     # LMH_SCHED: experiments only
     # machine LICM off: in the fused rollout loop it hoists ~100 literal constants (libm polynomial coefficients, LDS offsets) into VGPRs
     # that stay live for the whole launch -> 256 VGPRs + scratch spills; without it the kernel needs 178 VGPRs and no scratch.
     if os.environ.get("LMH_KEEP_MACHINE_LICM") != "1":
