@@ -213,6 +213,10 @@ __shared__ double *g_dbg;
 #define SET_GDBG(p) do { if (LANE == 0) g_dbg = (p); } while (0)
 // per-wave timeline (two-wave debug kernel): wave w stamps slot 3700 + 100 w + i (scripts/gpu_wave_timeline.py)
 #define WSTAMP(i) do { if (g_dbg && LANE == 0) g_dbg[3700 + 100 * (int)(threadIdx.x >> 6) + (i)] = (double)clock64(); } while (0)
+#elif defined(LMH_PMARK)                 // static instruction census: the stamps become comments in the ISA listing (scripts/isa_census.py)
+#define SUBSTAMP(i) do { } while (0)
+#define SET_GDBG(p) do { } while (0)
+#define WSTAMP(i) asm volatile("; PMARK " #i)
 #else
 #define SUBSTAMP(i) do { } while (0)
 #define SET_GDBG(p) do { } while (0)
