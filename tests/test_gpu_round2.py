@@ -622,7 +622,9 @@ def test_rccl_collectives_of_the_bench_on_device_tensors(cfg2):
     summary = sharding.make_summary(st, out, status, ctl)
     assert summary.is_cuda
     assert not dist.is_initialized()
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
         dist.barrier(device_ids=[torch.cuda.current_device()])
         g = sharding.gather_summaries(summary, 1, 0)
