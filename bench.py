@@ -51,7 +51,7 @@ DEFAULTS = {2: dict(instances=1024, ticks=10, horizon=16, max_ticks=230),
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--steps", type=int, default=32)        # 32 launches x 16 ms: a timed region above 0.5 s on the default workload
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4),
                     help="BASELINE config number (1-based); default 3 at --gpus 1, 4 (randomised models + IK kernel in set-up) otherwise")
