@@ -376,9 +376,9 @@ def main():
     done = 0
     flags_acc = torch.zeros((), dtype=torch.int32, device=ctl.device)
 
-    host = None
+    pinned = None
     if args.host_io:
-        host = dict(state=state.cpu().pin_memory(), out=torch.empty(out.shape, dtype=out.dtype).pin_memory(),
+        pinned = dict(state=state.cpu().pin_memory(), out=torch.empty(out.shape, dtype=out.dtype).pin_memory(),
                     status=torch.empty(status.shape, dtype=status.dtype).pin_memory(),
                     log=None if log is None else torch.empty(log.shape, dtype=log.dtype).pin_memory())
 
@@ -387,16 +387,16 @@ def main():
         if done and done % reset_every == 0:
             state.copy_(state0)                                   # device-to-device, inside the timed region when it happens
             status.zero_()
-            if host is not None:
-                host["state"].copy_(state0, non_blocking=True)
-        if host is not None:
-            state.copy_(host["state"], non_blocking=True)         # the caller's state arrives over PCIe ...
+            if pinned is not None:
+                pinned["state"].copy_(state0, non_blocking=True)
+        if pinned is not None:
+            state.copy_(pinned["state"], non_blocking=True)         # the caller's state arrives over PCIe ...
         ctl.rollout(state, args.ticks, out, status, log)
-        if host is not None:                                       # ... and everything the rollout produced goes back
-            host["state"].copy_(state, non_blocking=True); host["out"].copy_(out, non_blocking=True)
-            host["status"].copy_(status, non_blocking=True)
+        if pinned is not None:                                       # ... and everything the rollout produced goes back
+            pinned["state"].copy_(state, non_blocking=True); pinned["out"].copy_(out, non_blocking=True)
+            pinned["status"].copy_(status, non_blocking=True)
             if log is not None:
-                host["log"].copy_(log, non_blocking=True)
+                pinned["log"].copy_(log, non_blocking=True)
         done += 1
 
     for _ in range(args.warmup):
