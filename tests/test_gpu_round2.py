@@ -537,6 +537,10 @@ def test_bench_default_line_shape():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["cpu_model"]
     assert cb["parity_vs_gpu_last_tick_max_rel"] < 1e-6
     assert cb["literal_2wbc_value"] and cb["literal_2wbc_value"] < cb["value"] * 1.05
+    # the informational PCIe-inclusive mode runs the same rollouts (and keeps the CPU leg's inputs intact)
+    hio = _run_bench(["--instances", "128", "--steps", "3", "--warmup", "1", "--ticks", "10", "--cpu-seconds", "3", "--host-io"])
+    assert hio["config"]["host_io_over_pcie"] is True and hio["instances_flagged"] == 0 and hio["cpu_baseline"]["value"] > 0
+    assert hio["cpu_baseline"]["parity_vs_gpu_last_tick_max_rel"] < 1e-6
 
 
 # ------------------------------------------------------------------------------- BASELINE config 5: fp32-vs-fp64 tolerance sweep
