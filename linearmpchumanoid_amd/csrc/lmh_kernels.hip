@@ -160,7 +160,8 @@ enum {
     // ---- phase B, NU = 15 (qp_setup15): every matrix-core operand is stored so that a lane's fragment is base + constant * k-step,
     // zero-padded to the tile shape (rows beyond the matrix point at Q_ZERO), so the tiles run without bounds selects
     // row strides are padded (34, 18, 17, 10 doubles) so that the 16 rows a fragment load touches fall into different LDS banks
-    Q_U = S0 + 0,      // 16 x 34 : U = [AG_lin ; J] rows, columns 30, 31 and row 15 zero
+    Q_U = S0 + 0,      // 16 x 34 : U rows in the order [J (12) ; AG_lin (3) ; zero row], columns 30, 31 zero (the Jacobian rows are written
+                       //           early by wave 0, qp_prefill15: they and their U D^-1 image must stay inside S0 + [0, 408) and [544, 952))
     Q_UD = S0 + 544,   // 16 x 34 : U D^-1
     Q_BPT = S0 + 1088, // 8 x 34  : rows 0..6 = columns of bp' = [-qref | D^-1 Mb'], row 7 = -qref + D^-1 U' Om beta (V's g column)
     Q_TT = S0 + 1360,  // 8 x 18  : V' then t'' (row n = right-hand side n, k contiguous, [15] zero)
@@ -2162,13 +2163,6 @@ __device__ __forceinline__ v4d mfma_ptr(const double *a0, const double *b0)
     return acc + acc2;
 }
 
-// QP set-up for the reference's weights (angular-momentum weight 0: U = [AG_lin ; J] has 15 rows), controller.cpp:94-132 + the equality
-// blocks of :388-436, down to the cone problem data W, h, qv.  Same algebra as qp_setup<NU> below with two changes of association that
-// shorten the leading wave's path:
-//   * Cm ob - beta = U D^-1 U' ob, so the right-hand side fix-up becomes a column of bp' (q = D^-1 U' Om beta, formed beside the fills);
-//   * S | d = Mb Y = Mb bp' - (Mb D^-1 U') t'' : Z = Mb D^-1 U' and Mb bp' do not depend on the 15 x 15 solve and are formed by the helper
-//     wave while wave 0 solves; the Y tiles (needed only by the recovery) are formed by the helper wave while wave 0 goes on to S^-1, W, h.
-// NW = 2 joins: fills | Cm, q+V | solve, Z+Mbp | (S..qv), Y | -> the caller's join in front of the cone solve.
 // The Jacobian rows of U and U D^-1 (rows 0..11 of the padded operands).  They depend on wave 0's own products only and land in LDS that is
 // dead once its Newton-Euler pass is over (S0 + [0, 408) and S0 + [544, 952): the NE sweeps' scratch and the FK transforms), so on the
 // two-wave schedule wave 0 writes them while wave 1 is still inside CRBA / its reference chain, ahead of the join.
@@ -2188,6 +2182,14 @@ __device__ __forceinline__ void qp_prefill15(double *L, const LmhDevParams &P)
     }
 }
 
+// QP set-up for the reference's weights (angular-momentum weight 0: U = [J ; AG_lin] has 15 rows; the row order is a free choice, the
+// solve permutes with it), controller.cpp:94-132 + the equality
+// blocks of :388-436, down to the cone problem data W, h, qv.  Same algebra as qp_setup<NU> below with two changes of association that
+// shorten the leading wave's path:
+//   * Cm ob - beta = U D^-1 U' ob, so the right-hand side fix-up becomes a column of bp' (q = D^-1 U' Om beta, formed beside the fills);
+//   * S | d = Mb Y = Mb bp' - (Mb D^-1 U') t'' : Z = Mb D^-1 U' and Mb bp' do not depend on the 15 x 15 solve and are formed by the helper
+//     wave while wave 0 solves; the Y tiles (needed only by the recovery) are formed by the helper wave while wave 0 goes on to S^-1, W, h.
+// NW = 2 joins: fills | Cm, q+V | solve, Z+Mbp | (S..qv), Y | -> the caller's join in front of the cone solve.
 template <int NW>
 __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int wid, double *dbgp)
 {
