@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: control ticks/s/node of the batched NAO WBC+MPC closed loop.
 
-One "step" = one launch of the fused rollout kernel = `--ticks` RK4 control ticks (4 controller
-evaluations each) for every robot instance of this rank.
+One "step" = ONE launch of the fused rollout kernel = one whole rollout segment of `--ticks` RK4 control ticks (4 controller
+evaluations each) for every robot instance of this rank: 4 000 ticks (config 3 / 4: SURVEY 8d's length) or 2 000 (config 2 / 5).
+The control step is dt = 1 ms; the LIPM preview is sampled at mpc_dt = 10 ms (config 2: 20 ms), so N = 32 samples preview 0.32 s and
+the closed loop is stable over any number of ticks: consecutive steps CONTINUE the same rollouts (config 3: every step walks eight
+more 0.5 s steps), nothing is restarted, no launch boundary sits inside a step.
 
 Workloads (BASELINE.json configs):
   --config 3 (default at --gpus 1): configs[2], the largest single-GPU configuration: 4096 NAO instances, walking
-      (footRefTrajectory swing polynomials + piecewise ZMP, contact switching DS / SS-R / SS-L), per-instance step
-      length U(0.02, 0.05) m (seed 20260003 + i), dt = 1 ms, LIPM-MPC horizon N = 32, warm-started WBC QP, log on.
+      (footRefTrajectory swing polynomials + piecewise ZMP, contact switching DS / SS-R / SS-L, timePerStep 0.5 s with 0.2 s of double
+      support), per-instance step length U(0.02, 0.05) m (seed 20260003 + i), dt = 1 ms, LIPM-MPC horizon N = 32 x 10 ms, warm-started
+      WBC QP, tau | f log on.
   --config 4 (default at --gpus N > 1): configs[3], one GPU's share of it per rank: as config 3 plus per-link mass
       x U(0.9, 1.1) and CoM +- 5 mm (seed 20260004 + i), start posture per instance from the IK KERNEL, per-instance
       LIPM height; the end-of-run RCCL gather of 128-B summaries is inside the timed region.
-  --config 2: configs[1]: 1024 instances, balance task with velocity pushes, N = 16 (round 1's bench line).
+  --config 2: configs[1]: 1024 instances, balance task with velocity pushes (SURVEY's seeds at half amplitude: inside the capture
+      region of the support polygon), N = 16 x 20 ms.
+  --config 5: configs[4], one GPU's share: 4096 instances, jump schedule (stance 0.4 s, flight 0.15 s, double support), N = 48 x 10 ms;
+      one step = one jump from the initial state (the schedule is not periodic: restarted per step, reported).
+  --coupled: round 1-2's line for continuity: mpc_dt = dt (the reference app's own choice of one value for Clock, ZMP and Mpc3dLip),
+      40 (config 2: 10) ticks per step, rollouts restarted inside their ~0.5 s validity range.
 
 `--gpus N` with no RANK in the environment starts N child processes of this script (one per GPU, before anything
 touches the GPU) and relays rank 0's JSON line; under torchrun (RANK set) it is one rank.  Ranks shard instances
@@ -36,57 +45,77 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak = 256 CU x 64 lanes x 2 flop x 2.4 GHz
 FP64_MFMA_PEAK_TFLOPS = 78.6     # v_mfma_f64_16x16x4_f64: fp64 matrix rate = fp64 vector rate on gfx950
 MFMA_MOP_FLOP = 512              # SQ_INSTS_VALU_MFMA_MOPS_F64 unit (one 16x16x4 f64 MFMA = 2048 flop = 4 MOPS)
-PROFILE_TAGS = {3: "r02_c3", 2: "r02_c2"}   # profiles/<tag>_rollout_summary.json: PMC passes of the committed kernel
+PROFILE_TAGS = {3: "r03_c3", 2: "r03_c2"}   # profiles/<tag>_rollout_summary.json: PMC passes of the committed kernel on the default command
+HARD_FLAGS = 1 | 2 | 4 | 8       # LMH_FLAG_QP_MAXITER | NONFINITE | ZMP_RANGE | NOT_SPD; LMH_FLAG_QP_FP64_ROUTE (16) is informational
 
-# max_ticks: the tick range in which the closed loop is valid.  Every BASELINE config pairs the 1 kHz control rate with a preview of
-# N <= 48 samples = 16..48 ms (the reference couples the MPC sample time to the control step, mpcLinearPendulum.cpp:43,92), far shorter
-# than the LIPM's unstable time constant sqrt(z/g) = 0.16 s: the loop (which integrates the controller's own acceleration,
-# apps/offline/main.cpp:118-121) drifts out of range after ~0.5-0.6 s, in the CPU oracle exactly as on the GPU (DESIGN.md "Long runs").
-# Rollouts therefore restart from their initial states every max_ticks ticks; restarts inside the timed region are reported.
-DEFAULTS = {2: dict(instances=1024, ticks=10, horizon=16, max_ticks=230),
-            3: dict(instances=4096, ticks=40, horizon=32, max_ticks=480),
-            4: dict(instances=4096, ticks=40, horizon=32, max_ticks=480)}
+# One step = `ticks` ticks in one launch.  mpc_dt: MPC sample time / reference sample period (lmh_config.mpc_dt); the preview spans
+# horizon x mpc_dt = 0.32 s (0.48 s for the jump) -- with the preview tied to the 1 ms control step (16..48 ms, far below the LIPM's time
+# constant sqrt(z/g) = 0.16 s) every loop diverges after ~0.5 s, which is what --coupled reproduces.  push: amplitude factor on SURVEY's
+# U(-0.3, 0.3) m/s pushes (beyond 0.18 m/s backwards the capture point leaves the heel: such robots fall whatever the controller does).
+DEFAULTS = {2: dict(instances=1024, ticks=2000, horizon=16, mpc_dt=2e-2, push=0.5, reset_every=0),
+            3: dict(instances=4096, ticks=4000, horizon=32, mpc_dt=1e-2, reset_every=0),
+            4: dict(instances=4096, ticks=4000, horizon=32, mpc_dt=1e-2, reset_every=0),
+            5: dict(instances=4096, ticks=2000, horizon=48, mpc_dt=1e-2, reset_every=1)}
+WALK = dict(step_time=0.5, ds_time=0.2, settle_time=0.3)
+# --coupled (rounds 1-2): mpc_dt = dt; max_ticks = the range in which that loop stays finite
+COUPLED = {2: dict(instances=1024, ticks=10, horizon=16, max_ticks=230, push=1.0),
+           3: dict(instances=4096, ticks=40, horizon=32, max_ticks=480),
+           4: dict(instances=4096, ticks=40, horizon=32, max_ticks=480)}
+COUPLED_WALK = dict(step_time=0.2, ds_time=0.05, settle_time=0.1)
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)        # 32 launches x 16 ms: a timed region above 0.5 s on the default workload
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4),
+    ap.add_argument("--steps", type=int, default=8)         # 8 launches x ~1.4 s on the default workload
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5),
                     help="BASELINE config number (1-based); default 3 at --gpus 1, 4 (randomised models + IK kernel in set-up) otherwise")
+    ap.add_argument("--coupled", action="store_true", help="rounds 1-2's line: mpc_dt = dt, short steps, rollouts restarted inside their validity range")
     ap.add_argument("--instances", type=int, default=None, help="robot instances per GPU")
     ap.add_argument("--ticks", type=int, default=None, help="RK4 ticks per step (per launch)")
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--mpc-dt", type=float, default=None, help="MPC sample time (lmh_config.mpc_dt); default per config, dt with --coupled")
     ap.add_argument("--cold", action="store_true", help="cold-start the QP active set every evaluation")
     ap.add_argument("--no-log", action="store_true", help="do not write the per-tick tau|f log")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (all of its lines together)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (all of its lines together)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--reset-every", type=int, default=None,
-                    help="restart the rollouts from the initial states after this many steps; default: as many steps as fit the "
-                         "config's valid tick range (config 3/4: 480 ticks = settle, DS, SS-R, DS, SS-L of the walking plan; config 2: 230 ticks; "
-                         "see DEFAULTS / DESIGN.md 'Long runs')")
+                    help="restart the rollouts from the initial states after this many steps (0 = never: consecutive steps continue the same "
+                         "rollouts); default: 0 for configs 2-4, 1 for the jump of config 5, the validity range with --coupled")
     ap.add_argument("--summary-out", default=None, help="write the gathered end-of-run summary (lmh_write_summary format) to this path")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from rocprofv3 --pmc; default: the committed profiles/ summary when the workload matches it")
-    ap.add_argument("--step-time", type=float, default=0.2, help="walking: time per step (double + single support) [s]")
-    ap.add_argument("--ds-time", type=float, default=0.05, help="walking: double-support share of a step [s]")
-    ap.add_argument("--settle-time", type=float, default=0.1, help="walking: stance before the first step [s]")
-    ap.add_argument("--precision", type=int, default=0, help="lmh_config.precision (0 fp64, 1 mixed, 2 fp32)")
+    ap.add_argument("--step-time", type=float, default=None, help="walking: time per step (double + single support) [s]")
+    ap.add_argument("--ds-time", type=float, default=None, help="walking: double-support share of a step [s]")
+    ap.add_argument("--settle-time", type=float, default=None, help="walking: stance before the first step [s]")
+    ap.add_argument("--push", type=float, default=None, help="config 2: amplitude factor on SURVEY's U(-0.3, 0.3) m/s pushes")
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2), help="lmh_config.precision (0 fp64, 1 mixed, 2 fp32)")
+    ap.add_argument("--max-qp-iters", type=int, default=None, help="diagnostic: lmh_config.max_qp_iters (a low cap raises LMH_FLAG_QP_MAXITER: exercises the flag accounting / exit code 3)")
     ap.add_argument("--host-io", action="store_true",
                     help="informational: every step also moves the state host->device and out | status | log device->host through pinned "
                          "buffers (what a caller holding HOST buffers pays over PCIe); never the default line")
     args = ap.parse_args(argv)
     if args.config is None:
         args.config = 3 if args.gpus == 1 else 4
-    d = DEFAULTS[args.config]
+    if args.coupled and args.config == 5:
+        ap.error("--coupled has no config 5 line")
+    d = dict((COUPLED if args.coupled else DEFAULTS)[args.config])
     for k in ("instances", "ticks", "horizon"):
         if getattr(args, k) is None:
             setattr(args, k, d[k])
+    if args.mpc_dt is None:
+        args.mpc_dt = args.dt if args.coupled else d["mpc_dt"]
+    if args.push is None:
+        args.push = d.get("push", 1.0)
+    w = COUPLED_WALK if args.coupled else WALK
+    for k in ("step_time", "ds_time", "settle_time"):
+        if getattr(args, k) is None:
+            setattr(args, k, w[k])
     if args.reset_every is None:
-        args.reset_every = max(1, d["max_ticks"] // args.ticks)
+        args.reset_every = max(1, d["max_ticks"] // args.ticks) if args.coupled else d["reset_every"]
     return args
 
 
@@ -154,23 +183,28 @@ def randomised_links(first, count, seed=20260004):
 
 def build_workload(args, ctl, first, count, total_ticks):
     """Uploads models / references for this rank's instances; returns (state0 tensor, dict of host-side inputs the
-    CPU baseline replays)."""
+    CPU baseline replays).  Reference arrays are sampled at the MPC sample time (args.mpc_dt)."""
     import numpy as np
     import torch
     from linearmpchumanoid_amd import trajectories
     from linearmpchumanoid_amd.controller import ik_start_posture, initial_configuration
     dev = ctl.device_index
     host = {}
-    if args.config == 2:
+    sim_time = total_ticks * args.dt + 1.0                         # the preview window [k, k + N] of the last tick stays inside the arrays
+    if args.config in (2, 5):
         q0, zcom = ik_start_posture(dev)
         ctl.set_zcom(np.array([zcom]))
-        ctl.set_refs_stance(total_ticks * args.dt + 1.0, 2)
-        v = perturbed_velocities(first, count)
+        if args.config == 2:
+            ctl.set_refs_stance(sim_time, 2)
+            v = args.push * perturbed_velocities(first, count)
+        else:                                                      # SURVEY 8d config 5: DS 0.4 s -> flight 0.15 s -> DS, small pushes
+            ctl.gen_jump(sim_time, 0.4, 0.15)
+            v = 0.2 * perturbed_velocities(first, count, seed=20260005)
+        plan = ctl.get_refs()
         state = ctl.new_state(q0, v, t=0.0)
-        zx, zy = trajectories.stance_zmp(total_ticks * args.dt + 1.0, args.dt, 2)
-        host.update(q0=np.tile(q0, (count, 1)), v=v, zcom=np.array([zcom]), zmp_x=zx, zmp_y=zy, phase=None, segs=None, sos=None, xscale=None, raw=None)
+        host.update(q0=np.tile(q0, (count, 1)), v=v, zcom=np.array([zcom]), zmp_x=plan["zmp_x"], zmp_y=plan["zmp_y"],
+                    phase=plan["phase"] if args.config == 5 else None, segs=None, sos=None, xscale=None, raw=None)
         return state, host
-    sim_time = total_ticks * args.dt + 0.5
     n_steps = max(2, int((sim_time - args.settle_time) / args.step_time))
     # the walking plan (ZMP samples, support phase, swing-foot polynomial segments) is generated ON THE DEVICE (lmh_gen_walk); it is read
     # back only so that the CPU baseline leg replays exactly the same references
@@ -200,10 +234,12 @@ def build_workload(args, ctl, first, count, total_ticks):
     return state, host
 
 
+_LOOP = "dt={dt} (control), LIPM-MPC horizon N={N} x mpc_dt={md}, WBC QP per evaluation, RK4 closed loop"
 WORKLOAD_TEXT = {
-    2: "{B} NAO instances/GPU, balance task (IK posture + velocity perturbation), dt={dt}, LIPM-MPC horizon N={N}, WBC QP per evaluation, RK4 closed loop",
-    3: "{B} NAO instances/GPU, walking (footRefTrajectory swing polynomials + piecewise ZMP, contact switching DS/SS-R/SS-L, per-instance step length U(0.02,0.05) m), dt={dt}, LIPM-MPC horizon N={N}, WBC QP per evaluation, RK4 closed loop",
-    4: "{B} NAO instances/GPU, walking with contact switching, domain-randomised link mass/CoM, per-instance IK start posture (IK kernel in set-up) and LIPM height, dt={dt}, LIPM-MPC horizon N={N}, WBC QP per evaluation, RK4 closed loop, end-of-run summary gather in the timed region",
+    2: "{B} NAO instances/GPU, balance task (IK posture + velocity pushes {push} x U(-0.3,0.3) m/s), " + _LOOP,
+    3: "{B} NAO instances/GPU, walking (footRefTrajectory swing polynomials + piecewise ZMP, contact switching DS/SS-R/SS-L, timePerStep {st} s, per-instance step length U(0.02,0.05) m), " + _LOOP,
+    4: "{B} NAO instances/GPU, walking with contact switching (timePerStep {st} s), domain-randomised link mass/CoM, per-instance IK start posture (IK kernel in set-up) and LIPM height, " + _LOOP + ", end-of-run summary gather in the timed region",
+    5: "{B} NAO instances/GPU, jump schedule (double support 0.4 s, flight 0.15 s, double support), " + _LOOP,
 }
 
 
@@ -249,16 +285,18 @@ def _native_oracle():
     return C.CDLL(out)
 
 
-def cpu_baseline(args, host, total_ticks, gpu_out=None):
+def cpu_baseline(args, host, step_ticks, gpu_replay=None):
     """Reference CPU path = the C oracle (restatement of the reference, dense cold-start active-set QP per evaluation), timed on
-    this host's cores on a bounded sample of the SAME workload: the first n robots of rank 0 over the same tick range the
-    GPU ran (warm-up + timed steps), static partition over threads.  Lines: one core; all usable cores (the reported value);
-    all cores with the reference's literal duplicate WBC call + per-call MPC Hessian rebuild (apps/offline/main.cpp:103-105,
-    mpcLinearPendulum.cpp:89-90); all cores with -O3 -march=native."""
+    this host's cores on a bounded sample of the SAME workload: the first n robots of rank 0 over ticks 0..T of the first step
+    (T = a whole step when the budget allows, otherwise its first T ticks), static partition over threads.  Lines: one core; all
+    usable cores (the reported value); all cores with the reference's literal duplicate WBC call + per-call MPC Hessian rebuild
+    (apps/offline/main.cpp:103-105, mpcLinearPendulum.cpp:89-90); all cores with -O3 -march=native.
+    gpu_replay(n_inst, nticks) -> [n_inst, 36]: the GPU's k4-stage tau | f of tick nticks - 1 for the same robots from the same
+    initial states (untimed), compared with the CPU leg's."""
     import numpy as np
     from oracle import pyoracle
     model, logical, usable, quota = host_cpu_info()
-    th = args.horizon * args.dt
+    th = args.horizon * args.mpc_dt + 1e-9
     B = host["q0"].shape[0]
 
     def run(idx, nticks, nthreads, wbc_calls=1, lib=None):
@@ -266,17 +304,17 @@ def cpu_baseline(args, host, total_ticks, gpu_out=None):
         zc = host["zcom"] if len(host["zcom"]) == 1 else host["zcom"][idx]
         return pyoracle.batch_rollout_ex(st, 0.0, args.dt, nticks, th, host["zmp_x"], host["zmp_y"], host["phase"], host["segs"], host["sos"],
                                          None if host["xscale"] is None else host["xscale"][idx], zc,
-                                         None if host["raw"] is None else host["raw"][idx], nthreads=nthreads, wbc_calls=wbc_calls, lib_override=lib)
+                                         None if host["raw"] is None else host["raw"][idx], nthreads=nthreads, wbc_calls=wbc_calls, lib_override=lib,
+                                         mpc_dt=args.mpc_dt)
 
     sec, _, _ = run(np.arange(1), 20, 1)                         # calibrate: 1 robot x 20 ticks on one core
     per_tick = sec / 20
     budget = args.cpu_seconds / 4.0                                # four lines
-    nt_full = total_ticks
-    per_robot = per_tick * nt_full
-    if per_robot <= budget:                                        # whole tick range per robot, as many robots as the budget allows
+    per_robot = per_tick * step_ticks
+    if per_robot <= budget:                                        # a whole step per robot, as many robots as the budget allows
         r = max(1, int(budget / per_robot))
-        n_inst, nticks = min(B, usable * r), nt_full
-    else:                                                          # range too long for the budget: one robot per thread, truncated range
+        n_inst, nticks = min(B, usable * r), step_ticks
+    else:                                                          # step too long for the budget: one robot per thread, its first ticks
         n_inst, nticks = min(B, usable), max(20, int(budget / per_tick))
     idx = np.arange(n_inst)
     n1 = max(20, min(nticks, int(budget / per_tick)))
@@ -287,11 +325,12 @@ def cpu_baseline(args, host, total_ticks, gpu_out=None):
            "single_core_value": n1 / sec1, "cpu_model": model, "logical_cpus": logical, "cgroup_cpu_quota": quota,
            "compiler_flags": "-O2 (reference's own CMake: -O1 -g + ASan/UBSan)",
            "seconds": secN,
-           "sample": f"C oracle, first {n_inst} robots of the same workload x ticks 0..{nticks} of the {nt_full} the GPU ran, {usable} threads (static partition), "
+           "sample": f"C oracle, first {n_inst} robots of the same workload x ticks 0..{nticks} of the {step_ticks}-tick step the GPU runs, {usable} threads (static partition), "
                      f"1 WBC solve per evaluation, cold-start dense active-set QP; single core: 1 robot x {n1} ticks"}
-    if gpu_out is not None and nticks == nt_full:                  # same robots, same tick count: the k4-stage tau|f of the last tick must agree
+    if gpu_replay is not None:                                     # same robots, same tick count: the k4-stage tau|f of the last tick must agree
+        g = gpu_replay(n_inst, nticks)
         ref = outN
-        err = float(np.max(np.abs(gpu_out[:n_inst, :36] - ref) / np.maximum(1e-9 * np.abs(ref).max(), np.abs(ref).max(axis=1, keepdims=True))))
+        err = float(np.max(np.abs(g[:n_inst, :36] - ref) / np.maximum(1e-9 * np.abs(ref).max(), np.abs(ref).max(axis=1, keepdims=True))))
         res["parity_vs_gpu_last_tick_max_rel"] = err
     try:
         sec2, _, _ = run(idx, nticks, usable, wbc_calls=2)
@@ -311,19 +350,23 @@ def cpu_baseline(args, host, total_ticks, gpu_out=None):
 
 
 def profiled_pmc(args):
-    """PMC figures per launch from the committed rocprofv3 passes (profiles/<tag>_rollout_summary.json, made by
-    scripts/profile_rollout.sh + scripts/summarise_profile.py on this same default command); only valid for the workload they
-    were collected on.  Returns (hbm traffic bytes per launch or None, MFMA f64 MOPS per evaluation or None, tag)."""
+    """PMC figures from the committed rocprofv3 passes (profiles/<tag>_rollout_summary.json, made by scripts/profile_rollout.sh +
+    scripts/summarise_profile.py on this same default command); only valid for the workload they were collected on.
+    Returns dict(traffic = HBM bytes per launch, mops = MFMA f64 MOPS per evaluation, flop_eval = counted fp64 flop per evaluation
+    (VALU FMA/ADD/MUL/TRANS classes x 64 lanes + MFMA), tag) or None."""
     tag = PROFILE_TAGS.get(args.config)
     d = DEFAULTS[args.config]
-    if tag is None or (args.instances, args.ticks, args.horizon) != (d["instances"], d["ticks"], d["horizon"]) or args.cold or args.precision:
-        return None, None, None
+    if (tag is None or args.coupled or (args.instances, args.ticks, args.horizon, args.mpc_dt) != (d["instances"], d["ticks"], d["horizon"], d["mpc_dt"])
+            or args.cold or args.precision or args.no_log):
+        return None
     try:
         with open(os.path.join(ROOT, "profiles", tag + "_rollout_summary.json")) as f:
             dd = json.load(f)["derived"]
-        return (dd["hbm_write_bytes_per_launch"] + dd["hbm_fetch_bytes_per_launch_x2_gfx950_correction"], dd["mfma_f64_mops_per_eval"], tag)
+        return dict(traffic=dd["hbm_write_bytes_per_launch"] + dd["hbm_fetch_bytes_per_launch_x2_gfx950_correction"],
+                    mops=dd["mfma_f64_mops_per_eval"], flop_eval=dd.get("counted_fp64_flop_per_eval"),
+                    flop_note=dd.get("counted_fp64_flop_note"), tag=tag)
     except Exception:
-        return None, None, None
+        return None
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -347,22 +390,27 @@ def main():
     from linearmpchumanoid_amd.controller import BatchedController, default_config
     from linearmpchumanoid_amd import sharding
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     if os.environ.get("LMH_BENCH_DEVICE") is not None:          # rehearsal of N>1 on a one-GPU box (gloo): all ranks share a card
         local_rank = int(os.environ["LMH_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)                             # before the process group: RCCL binds its communicator to this device
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     B = args.instances
     first, count = sharding.shard_range(B * world, world, rank)
-    th = args.horizon * args.dt
-    cfg = default_config(dt=args.dt, time_horizon=th, z_com=0.26, warm_start=0 if args.cold else 1, precision=args.precision)
+    th = args.horizon * args.mpc_dt + 1e-9                         # int(th / mpc_dt) == N whatever the rounding of the quotient
+    cfg = default_config(dt=args.dt, time_horizon=th, z_com=0.26, mpc_dt=0.0 if args.coupled else args.mpc_dt,
+                         warm_start=0 if args.cold else 1, precision=args.precision)
+    if args.max_qp_iters is not None:
+        cfg.max_qp_iters = args.max_qp_iters
     ctl = BatchedController(count, cfg, device=local_rank)
-    reset_every = max(1, args.reset_every)
+    assert ctl.N == args.horizon, (ctl.N, args.horizon)
     n_launch = args.warmup + args.steps
-    total_ticks = min(n_launch, reset_every) * args.ticks
+    reset_every = max(0, args.reset_every)                         # 0: consecutive steps continue the same rollouts
+    total_ticks = (min(n_launch, reset_every) if reset_every else n_launch) * args.ticks
     state, host = build_workload(args, ctl, first, count, total_ticks)
     state0 = state.clone()
     out, status = ctl.new_out(), ctl.new_status()
@@ -374,7 +422,7 @@ def main():
         torch.cuda.synchronize()
 
     done = 0
-    flags_acc = torch.zeros((), dtype=torch.int32, device=ctl.device)
+    flags_acc = torch.zeros((count,), dtype=torch.int32, device=ctl.device)   # status flags OR-ed over EVERY launch (the kernel overwrites status[:, 2] per launch)
 
     pinned = None
     if args.host_io:
@@ -384,7 +432,7 @@ def main():
 
     def step():
         nonlocal done
-        if done and done % reset_every == 0:
+        if reset_every and done and done % reset_every == 0:
             state.copy_(state0)                                   # device-to-device, inside the timed region when it happens
             status.zero_()
             if pinned is not None:
@@ -392,6 +440,7 @@ def main():
         if pinned is not None:
             state.copy_(pinned["state"], non_blocking=True)         # the caller's state arrives over PCIe ...
         ctl.rollout(state, args.ticks, out, status, log)
+        flags_acc.bitwise_or_(status[:, 2])                       # same stream, no sync
         if pinned is not None:                                       # ... and everything the rollout produced goes back
             pinned["state"].copy_(state, non_blocking=True); pinned["out"].copy_(out, non_blocking=True)
             pinned["status"].copy_(status, non_blocking=True)
@@ -421,11 +470,13 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    flags = int((status[:, 2] != 0).sum().item())
+    hard = int(((flags_acc & HARD_FLAGS) != 0).sum().item())
+    routed = int(((flags_acc & 16) != 0).sum().item())
+    hard_last = int(((status[:, 2] & HARD_FLAGS) != 0).sum().item())
     if world > 1:
-        ft = torch.tensor([flags], dtype=torch.int64, device=ctl.device if args.backend == "nccl" else "cpu")
+        ft = torch.tensor([hard, routed, hard_last], dtype=torch.int64, device=ctl.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
-        flags = int(ft.item())
+        hard, routed, hard_last = int(ft[0].item()), int(ft[1].item()), int(ft[2].item())
     if rank == 0 and args.summary_out and gathered is not None:
         ctl.write_summary(args.summary_out, gathered.cpu().numpy(), dt=args.dt)
 
@@ -438,52 +489,69 @@ def main():
         units = count * args.ticks                                 # robot-ticks one launch processes
         alg_bytes = units * (ALG_BYTES_PER_TICK if log is not None else 960)
         alg_flop = units * ALG_FLOP_PER_TICK
-        traffic, mops, tag = profiled_pmc(args)
+        pmc = profiled_pmc(args)
+        traffic = args.traffic if args.traffic is not None else (pmc["traffic"] if pmc else None)
         fp64_t = alg_flop / launch_s / 1e12
         hbm_g = alg_bytes / launch_s / 1e9
-        mfma = None
-        if mops is not None:
-            mt = units * 4 * mops * MFMA_MOP_FLOP / launch_s / 1e12
+        mfma = counted = None
+        if pmc is not None:
+            mt = units * 4 * pmc["mops"] * MFMA_MOP_FLOP / launch_s / 1e12
             mfma = {"achieved_tflops": mt, "peak_tflops": FP64_MFMA_PEAK_TFLOPS, "frac": mt / FP64_MFMA_PEAK_TFLOPS,
-                    "mfma_f64_mops_per_eval": mops, "source": f"SQ_INSTS_VALU_MFMA_MOPS_F64 of the committed profile profiles/{tag}_rollout_summary.json x {MFMA_MOP_FLOP} flop"}
+                    "mfma_f64_mops_per_eval": pmc["mops"], "source": f"SQ_INSTS_VALU_MFMA_MOPS_F64 of the committed profile profiles/{pmc['tag']}_rollout_summary.json x {MFMA_MOP_FLOP} flop"}
+            if pmc.get("flop_eval"):
+                ct = units * 4 * pmc["flop_eval"] / launch_s / 1e12
+                counted = {"counted_flop_per_tick": 4 * pmc["flop_eval"], "achieved": ct, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ct / FP64_VALU_PEAK_TFLOPS, "note": pmc.get("flop_note"),
+                           "source": f"profiles/{pmc['tag']}_rollout_summary.json (rocprofv3 --pmc passes of this command)"}
+        restarts = ((n_launch - 1) // reset_every) if reset_every else 0
         res = {
             "metric": "control ticks/s/node (batched NAO WBC+MPC @1kHz)",
             "value": value, "unit": "control ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {0: "f64", 1: "f64 (QP) / f32 (model terms)"}[args.precision], "data": "synthetic",
-            "config": {"workload": WORKLOAD_TEXT[args.config].format(B=B, dt=args.dt, N=args.horizon), "baseline_config": args.config,
-                       "instances_per_gpu": B, "ticks_per_step": args.ticks, "evaluations_per_tick": 4,
-                       "tick_range": [args.warmup * args.ticks, n_launch * args.ticks] if n_launch <= reset_every
-                       else f"ticks 0..{reset_every * args.ticks} of every rollout, restarted from the initial states every {reset_every} launches (the closed loop leaves its valid range after that)",
+            "vs_baseline": None,
+            "dtype": {0: "f64", 1: "f64 (QP) / f32 (model terms)", 2: "f32 (model terms + QP), f64 state / references"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": WORKLOAD_TEXT[args.config].format(B=B, dt=args.dt, N=args.horizon, md=args.mpc_dt, push=args.push, st=args.step_time),
+                       "baseline_config": args.config, "coupled_mpc_dt": bool(args.coupled),
+                       "instances_per_gpu": B, "ticks_per_step": args.ticks, "evaluations_per_tick": 4, "mpc_dt": args.mpc_dt, "preview_s": args.horizon * args.mpc_dt,
+                       "tick_range": [args.warmup * args.ticks, n_launch * args.ticks] if not restarts
+                       else f"ticks 0..{reset_every * args.ticks} of every rollout, restarted from the initial states every {reset_every} step(s)",
                        "qp_start": "cold" if args.cold else "warm", "log": log is not None, "host_io_over_pcie": bool(args.host_io), "parallelism": f"instances sharded x{world}",
-                       "rollout_restarts": (n_launch - 1) // reset_every, "summary_gather_in_timed_region": True},
+                       "rollout_restarts": restarts, "summary_gather_in_timed_region": True},
             "evaluations_per_s": value * 4,
+            "timed_region_s": elapsed,
             "roofline": {"bound": "fp64-valu", "achieved": fp64_t, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64_t / FP64_VALU_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": None if traffic is None else f"committed profile profiles/{tag}_rollout_summary.json (WRITE_SIZE + 2 x FETCH_SIZE per launch)",
+                         "traffic": traffic, "traffic_source": None if traffic is None else ("--traffic" if args.traffic is not None else f"committed profile profiles/{pmc['tag']}_rollout_summary.json (WRITE_SIZE + 2 x FETCH_SIZE per launch)"),
                          "kernel": "lmh_rollout_kernel", "kernel_ms": kernel_ms, "units_per_launch": units,
                          "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "binding resource: fp64 vector issue + LDS latency (SURVEY 8d); nominal 8.0e5 flop per tick, not a counted figure",
+                         "nominal_flop_per_tick": ALG_FLOP_PER_TICK,
+                         "counted_flop_per_tick": None if counted is None else counted["counted_flop_per_tick"],
+                         "frac_counted": None if counted is None else counted["frac"],
+                         "counted": counted,
+                         "note": "binding resource: fp64 vector issue + LDS latency (SURVEY 8d); `frac` prices SURVEY's nominal 8.0e5 flop per tick, `frac_counted` the fp64 operations "
+                                 "the kernel actually issues (PMC instruction classes of the committed profile)",
                          "hbm": {"bound": "hbm", "achieved": hbm_g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_g / HBM_PEAK_GBS},
                          "mfma": mfma},
-            "instances_flagged": flags,
+            "instances_flagged": hard,
+            "flags_accumulated_over": f"all {n_launch} launches (warm-up included)", "instances_flagged_in_last_launch": hard_last,
+            "instances_fp64_route": routed,
             "summary_rows_gathered": int(gathered.shape[0]) if gathered is not None else 0,
         }
         if not args.no_cpu_baseline and world == 1:              # the CPU baseline is timed on rank 0 at N = 1 only
             try:
-                # parity sample for the CPU leg: one more (untimed) cycle from the initial states over the same tick range
-                state.copy_(state0); status.zero_()
-                for _ in range(total_ticks // args.ticks):
-                    ctl.rollout(state, args.ticks, out, status, log)
-                torch.cuda.synchronize()
-                g_out = out.cpu().numpy()
-                res["cpu_baseline"] = cpu_baseline(args, host, total_ticks, g_out)
+                def gpu_replay(n_inst, nticks):                   # parity sample for the CPU leg: the same robots from the initial states (untimed)
+                    state.copy_(state0); status.zero_()
+                    ctl.rollout(state, nticks, out, status, log)
+                    torch.cuda.synchronize()
+                    return out.cpu().numpy()
+                res["cpu_baseline"] = cpu_baseline(args, host, args.ticks, gpu_replay)
                 if res["cpu_baseline"].get("value"):
                     res["vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 res["cpu_baseline"] = {"value": None, "unit": "control ticks/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
-        if flags:
-            print(f"bench.py: {flags} instances raised a status flag inside the benchmarked tick range", file=sys.stderr)
+        if hard:
+            print(f"bench.py: {hard} instances raised a status flag in some launch of the benchmarked range", file=sys.stderr)
             rc = 3
     if world > 1:
         dist.barrier()

@@ -23,7 +23,7 @@
  *                                   xRef(3) | yRef(3) | pad(2)
  *       (WBCOutput, controller.hpp:43-48; Robot::getCoM/getComVel; Mpc3dLip::getXRef/getYRef)
  *   status [B][LMH_STATUS_STRIDE] int32 : k | qp_iterations | flags | active_mask
- *       k = int(t/dt) of the last evaluation (src/mpcLinearPendulum.cpp:92), bit-exact.
+ *       k = int(t/mpc_dt) of the last evaluation (src/mpcLinearPendulum.cpp:92), bit-exact.
  */
 #ifndef LMH_H
 #define LMH_H
@@ -76,8 +76,9 @@ enum {
  * include/linearMpcHumanoid/controller/controller.hpp:80-124, mpcLinearPendulum.hpp:43-49,
  * src/controller.cpp:117, apps/offline/main.cpp:13-14,38-39. */
 typedef struct lmh_config {
-    double dt;             /* control step == MPC sample time (mpcLinearPendulum.cpp:43,92) */
-    double time_horizon;   /* N = (int)(time_horizon / dt)                                   */
+    double dt;             /* control step: Clock(timeStep, ...) of the caller (apps/offline/main.cpp:18), the RK4 step of lmh_rollout;
+                              also the MPC sample time when mpc_dt == 0 (the reference's own app passes the same value to both)   */
+    double time_horizon;   /* N = (int)(time_horizon / mpc_dt)  (mpcLinearPendulum.cpp:43)                                       */
     double z_com;          /* LIPM height: Mpc3dLip ctor argument (main.cpp:39)              */
     double gravity, alpha, beta;
     double mu;
@@ -106,11 +107,18 @@ typedef struct lmh_config {
     double contact_d;      /* normal damping per vertex [N s/m]  */
     double contact_dt;     /* tangential damping per vertex [N s/m] */
     double contact_mu;     /* friction coefficient of the plant's ground */
+    /* MPC sample time: the `dt` argument of Mpc3dLip(dt, timeHorizon, zCom) (apps/offline/main.cpp:39, mpcLinearPendulum.hpp:10-13) and the
+     * `timeStep` of ZMP(task, simulationTime, timeStep, supportFoot) (main.cpp:21) -- the reference's caller picks them independently of the
+     * Clock's step (main.cpp:18).  It sets k = int(t / mpc_dt) on the float-accumulated clock (mpcLinearPendulum.cpp:92), the LIPM A, B
+     * (:45-47), the horizon N and the sample period of every reference array (ZMP x/y, support phase, segment index).
+     * 0 (the default) = dt: one value for both, as apps/offline/main.cpp passes.  E.g. dt = 1e-3, mpc_dt = 1e-2, time_horizon = 0.32:
+     * 1 kHz control with a 32 x 10 ms preview. */
+    double mpc_dt;
 } lmh_config;
 
 typedef struct lmh_handle lmh_handle;
 
-/* fills the reference literals; dt = 0.01, time_horizon = 0.5, z_com = 0.26 */
+/* fills the reference literals; dt = 0.01, mpc_dt = 0 (= dt), time_horizon = 0.5, z_com = 0.26 */
 void lmh_config_default(lmh_config *cfg);
 const char *lmh_last_error(void);
 int lmh_device_count(void);
@@ -138,7 +146,7 @@ void lmh_nominal_links(double *raw_links);
  * src/controller.cpp:14) + the support-phase extension.  HOST pointers, n_samples each;
  * phase may be NULL (all double support). */
 int lmh_set_refs(lmh_handle *h, const double *zmp_x, const double *zmp_y, const uint8_t *phase, int n_samples);
-/* replaces: ZMP::stanceZMP (src/zmpGeneration.cpp:39-60); support_foot: 0 Right,1 Left,2 Double */
+/* replaces: ZMP::stanceZMP (src/zmpGeneration.cpp:39-60) with timeStep = mpc_dt; support_foot: 0 Right,1 Left,2 Double */
 int lmh_set_refs_stance(lmh_handle *h, double simulation_time, int support_foot);
 /* replaces: footCoeffTrajectory output copied into Controller (src/footRefTrajectory.cpp:4-47,
  * src/controller.cpp:15-16).  coeff: HOST [3][8] ascending powers, n: [3] counts. */
@@ -154,7 +162,8 @@ int lmh_set_segments(lmh_handle *h, const double *segs, int n_seg, const uint16_
  * (zmpGeneration.hpp:15-19; walkZMP is never defined there) + one footCoeffTrajectory polynomial set per step
  * (footRefTrajectory.cpp:4-47, in closed form): settle_time of stance, then num_steps x [ds_time double support | single support],
  * first_support = LMH_PHASE_RIGHT or LMH_PHASE_LEFT, feet at y = -/+ foot_y; x in units of the step length (lmh_set_xscale).
- * Fills the ZMP / phase samples ((int)((simulation_time + 0.5) / dt) of them, as ZMP::stanceZMP counts) and 2 num_steps + 2 segments.
+ * Fills the ZMP / phase samples ((int)((simulation_time + 0.5) / mpc_dt) of them, as ZMP::stanceZMP counts; sample k <-> t = k mpc_dt)
+ * and 2 num_steps + 2 segments.
  * lmh_gen_jump: stance references with LMH_PHASE_FLIGHT in [stance_time, stance_time + flight_time) (BASELINE config 5). */
 int lmh_gen_walk(lmh_handle *h, double simulation_time, int num_steps, double time_per_step, double ds_time, double step_height,
                  double settle_time, int first_support, double foot_y);

@@ -48,7 +48,7 @@ class LmhConfig(C.Structure):
         "kp_joints", "kd_joints", "kp_mom", "kd_mom", "kp_feet", "kd_feet",
         "w_com_lin", "w_com_ang", "w_base_pos", "w_base_ang", "w_joints", "w_force", "w_foot",
         "eps_coeff")] + [("warm_start", C.c_int32), ("max_qp_iters", C.c_int32), ("precision", C.c_int32), ("bpp_rounds", C.c_int32),
-                                     ("plant", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_double) for n in ("contact_k", "contact_d", "contact_dt", "contact_mu")]
+                                     ("plant", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_double) for n in ("contact_k", "contact_d", "contact_dt", "contact_mu", "mpc_dt")]
 
 
 _lib = None

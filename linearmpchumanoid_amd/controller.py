@@ -15,7 +15,10 @@ from .capi import LmhConfig, check
 
 
 def default_config(dt=0.01, time_horizon=0.5, z_com=0.26, **overrides):
-    """lmh_config with the reference literals (controller.hpp:80-124, mpcLinearPendulum.hpp:43-49)."""
+    """lmh_config with the reference literals (controller.hpp:80-124, mpcLinearPendulum.hpp:43-49).
+
+    dt is the control step (Clock); mpc_dt=... (an override) is the MPC sample time / reference sample period
+    (Mpc3dLip and ZMP constructor arguments, apps/offline/main.cpp:21,39); 0 or absent = dt."""
     cfg = LmhConfig()
     capi.lib().lmh_config_default(C.byref(cfg))
     cfg.dt, cfg.time_horizon, cfg.z_com = dt, time_horizon, z_com

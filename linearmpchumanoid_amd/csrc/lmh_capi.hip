@@ -14,7 +14,7 @@
 #include "lmh_nao_model.h"
 
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s);
-extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
+extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, int *d_ticket, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s);
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s);
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s);
 extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const LmhIkTarget *target, int32_t *iters, hipStream_t s);
@@ -28,6 +28,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 struct lmh_handle {
     lmh_config cfg;
+    double mpc_dt = 0.0;              // resolved MPC sample time (cfg.mpc_dt, or cfg.dt when that is 0)
     int B = 0, device = 0, N = 0, n_models = 0, n_gain = 0, n_samples = 0;
     double *d_model = nullptr, *d_mpc = nullptr, *d_zx = nullptr, *d_zy = nullptr, *d_gcol = nullptr, *d_raw = nullptr;
     double *d_segs = nullptr, *d_xscale = nullptr;
@@ -40,9 +41,18 @@ struct lmh_handle {
     std::vector<double> h_state, h_out, h_gain;
     std::vector<int32_t> h_status;
     LmhDevParams P;
-    LmhDevParams *d_P = nullptr;      // device copy read by the rollout kernel
-    LmhDevParams P_dev;               // what d_P currently holds
-    bool P_dev_valid = false;
+    // Launch slots of lmh_rollout: the kernel reads its parameter block through a pointer and draws robots from a ticket word, so every
+    // launch in flight needs its own copy of both.  Slot i is reused by launch i + kSlots, after the event recorded behind launch i has
+    // completed (normally long ago): launches on different streams of one handle never share a block that is being rewritten.
+    static constexpr int kSlots = 8;
+    struct Slot {
+        LmhDevParams *d_P = nullptr;  // device copy read by the rollout kernel
+        int *d_ticket = nullptr;      // robot queue + departure count (two ints, zero between launches: the kernel resets them)
+        hipEvent_t done = nullptr;    // recorded behind the last launch that used this slot
+        LmhDevParams P_dev;           // what d_P currently holds
+        bool valid = false, used = false;
+    } slot[kSlots];
+    unsigned next_slot = 0;
 };
 
 extern "C" const char *lmh_last_error(void) { return g_err.c_str(); }
@@ -68,6 +78,7 @@ extern "C" void lmh_config_default(lmh_config *c)
     c->eps_coeff = 1e-8;                                            // controller.cpp:117
     c->warm_start = 1; c->max_qp_iters = 64; c->precision = LMH_PRECISION_FP64; c->bpp_rounds = 0;
     c->plant = 0; c->contact_k = 2.0e4; c->contact_d = 3.0; c->contact_dt = 3.0; c->contact_mu = 0.7;
+    c->mpc_dt = 0.0;                                                // = dt (apps/offline/main.cpp:18,21,39 pass one value to Clock, ZMP and Mpc3dLip)
 }
 
 extern "C" void lmh_nominal_links(double *raw) { std::memcpy(raw, kLmhNaoLinks, sizeof(kLmhNaoLinks)); }
@@ -75,10 +86,9 @@ extern "C" void lmh_nominal_links(double *raw) { std::memcpy(raw, kLmhNaoLinks, 
 // ---- Mpc3dLip::initialize (src/mpcLinearPendulum.cpp:41-68) + the algebraic gain row:
 // u = -H^-1 g, g = beta Pu'(Px x - z), H = alpha I + beta Pu'Pu  =>  u0 = -K (Px x - z),
 // K = beta e0' H^-1 Pu'.  Record layout: K | Px[:,0] | Px[:,1] | zcom | pad(3).
-static int build_gain_row(const lmh_config &c, double zcom, int N, double *rec)
+static int build_gain_row(const lmh_config &c, double dt /* MPC sample time */, double zcom, int N, double *rec)
 {
     const int n = N + 1;
-    const double dt = c.dt;
     std::vector<double> Pu((size_t)n * n, 0.0), H((size_t)n * n), h0(n, 0.0);
     double A[4] = {1, dt, 0, 1}, B[2] = {(dt * dt) / 2, dt}, Ap[4] = {1, 0, 0, 1};
     const double D = -zcom / c.gravity;
@@ -228,12 +238,13 @@ static void fill_params(lmh_handle *h)
     P.warm_start = c.warm_start; P.max_qp_iters = c.max_qp_iters; P.precision = c.precision;
     P.bpp_max = (c.bpp_rounds == 0) ? 10 : c.bpp_rounds;            // < 0: Lawson-Hanson from the empty set (diagnostic)
     P.plant = c.plant; P.contact_k = c.contact_k; P.contact_d = c.contact_d; P.contact_dt = c.contact_dt; P.contact_mu = c.contact_mu;
-    P.dt = c.dt;
+    P.dt = c.dt; P.mpc_dt = h->mpc_dt;
     P.kp_joints = c.kp_joints; P.kd_joints = c.kd_joints; P.kp_mom = c.kp_mom; P.kd_mom = c.kd_mom;
     P.kp_feet = c.kp_feet; P.kd_feet = c.kd_feet;
     P.w_com_lin = c.w_com_lin; P.w_com_ang = c.w_com_ang; P.w_base_pos = c.w_base_pos; P.w_base_ang = c.w_base_ang;
     P.w_joints = c.w_joints; P.w_force = c.w_force; P.w_foot = c.w_foot; P.eps_coeff = c.eps_coeff;
-    P.a00 = 1; P.a01 = c.dt; P.a10 = 0; P.a11 = 1; P.b0 = (c.dt * c.dt) / 2; P.b1 = c.dt;
+    const double md = h->mpc_dt;                                     // mpcLinearPendulum.cpp:45-47 with the Mpc3dLip ctor's dt
+    P.a00 = 1; P.a01 = md; P.a10 = 0; P.a11 = 1; P.b0 = (md * md) / 2; P.b1 = md;
 }
 
 static int upload_gain(lmh_handle *h, const double *zcom, int n)
@@ -241,7 +252,7 @@ static int upload_gain(lmh_handle *h, const double *zcom, int n)
     const int stride = 3 * (h->N + 1) + 4;
     h->h_gain.assign((size_t)n * stride, 0.0);
     for (int i = 0; i < n; i++)
-        if (build_gain_row(h->cfg, zcom[i], h->N, h->h_gain.data() + (size_t)i * stride))
+        if (build_gain_row(h->cfg, h->mpc_dt, zcom[i], h->N, h->h_gain.data() + (size_t)i * stride))
             return fail(LMH_ERR_BAD_ARG, "MPC Hessian not positive definite");
     if (h->d_mpc) { HIPCHK(hipFree(h->d_mpc)); h->d_mpc = nullptr; }
     HIPCHK(hipMalloc(&h->d_mpc, sizeof(double) * h->h_gain.size()));
@@ -256,6 +267,7 @@ static int upload_gain(lmh_handle *h, const double *zcom, int n)
 static const char *validate_config(const lmh_config *c)
 {
     if (!(c->dt > 0.0) || !(c->time_horizon > 0.0)) return "dt and time_horizon must be positive";
+    if (!(c->mpc_dt >= 0.0) || !std::isfinite(c->mpc_dt)) return "mpc_dt must be >= 0 (0 = dt)";
     if (!(c->z_com > 0.0) || !(c->gravity > 0.0)) return "z_com and gravity must be positive";
     if (!(c->alpha > 0.0) || !(c->beta > 0.0)) return "alpha and beta must be positive";
     if (!(c->mu > 0.0)) return "mu must be positive";
@@ -307,14 +319,15 @@ extern "C" int lmh_create(const lmh_config *cfg, int n_instances, int device, lm
     if (!cfg || !out || n_instances < 1) return fail(LMH_ERR_BAD_ARG, "lmh_create: bad argument");
     *out = nullptr;
     if (const char *why = validate_config(cfg)) return fail(LMH_ERR_BAD_ARG, std::string("lmh_create: ") + why);
-    const int N = (int)(cfg->time_horizon / cfg->dt);               // mpcLinearPendulum.cpp:43
-    if (N < 1 || N > LMH_MAX_HORIZON) return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/dt must be in [1, 64]");
+    const double mpc_dt = (cfg->mpc_dt > 0.0) ? cfg->mpc_dt : cfg->dt;
+    const int N = (int)(cfg->time_horizon / mpc_dt);                // mpcLinearPendulum.cpp:43
+    if (N < 1 || N > LMH_MAX_HORIZON) return fail(LMH_ERR_BAD_ARG, "horizon N = time_horizon/mpc_dt must be in [1, 64]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LMH_ERR_NO_DEVICE, "no HIP device: the controller has no CPU path");
     if (device < 0 || device >= ndev) return fail(LMH_ERR_BAD_ARG, "lmh_create: device index out of range");
     HIPCHK(hipSetDevice(device));
     lmh_handle *h = new lmh_handle();
-    h->cfg = *cfg; h->B = n_instances; h->device = device; h->N = N;
+    h->cfg = *cfg; h->B = n_instances; h->device = device; h->N = N; h->mpc_dt = mpc_dt;
     const int rc = create_body(h, cfg, n_instances);                // every failure path releases what was allocated so far
     if (rc != LMH_OK) { std::string keep = g_err; lmh_destroy(h); g_err = keep; return rc; }
     *out = h;
@@ -326,8 +339,13 @@ extern "C" int lmh_destroy(lmh_handle *h)
     if (!h) return LMH_OK;
     (void)hipSetDevice(h->device);
     void *bufs[] = {h->d_model, h->d_mpc, h->d_zx, h->d_zy, h->d_gcol, h->d_raw, h->d_phase, h->d_state, h->d_out, h->d_status,
-                    h->d_segs, h->d_xscale, h->d_sos, h->d_P};
+                    h->d_segs, h->d_xscale, h->d_sos};
     for (void *b : bufs) if (b) (void)hipFree(b);
+    for (auto &sl : h->slot) {
+        if (sl.done) { if (sl.used) (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
+        if (sl.d_P) (void)hipFree(sl.d_P);
+        if (sl.d_ticket) (void)hipFree(sl.d_ticket);
+    }
     delete h;
     return LMH_OK;
 }
@@ -390,7 +408,7 @@ extern "C" int lmh_set_refs(lmh_handle *h, const double *zx, const double *zy, c
 extern "C" int lmh_set_refs_stance(lmh_handle *h, double simulation_time, int support_foot)
 {
     if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
-    const int samples = (int)((simulation_time + 0.5) / h->cfg.dt);  // zmpGeneration.cpp:41
+    const int samples = (int)((simulation_time + 0.5) / h->mpc_dt);  // zmpGeneration.cpp:41 (timeStep_ = the MPC sample time)
     if (samples < 1) return fail(LMH_ERR_BAD_ARG, "no samples");
     std::vector<double> zx((size_t)samples, 0.0), zy((size_t)samples, (support_foot == 0) ? -0.05 : (support_foot == 1) ? 0.05 : 0.0);
     return lmh_set_refs(h, zx.data(), zy.data(), nullptr, samples);
@@ -459,7 +477,7 @@ extern "C" int lmh_get_mpc_gain(lmh_handle *h, double *K)
 static int ready(lmh_handle *h)
 {
     if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
-    if (!h->d_model || !h->d_mpc || !h->d_zx) return fail(LMH_ERR_NOT_READY, "model / references not set");
+    if (!h->d_model || !h->d_mpc || !h->d_zx || h->n_samples < 1) return fail(LMH_ERR_NOT_READY, "model / references not set");
     return LMH_OK;
 }
 
@@ -489,14 +507,23 @@ extern "C" int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_
     if (!d_state || !d_out || !d_status || n_ticks < 0) return fail(LMH_ERR_BAD_ARG, "bad argument");
     if (n_ticks == 0) return LMH_OK;
     HIPCHK(hipSetDevice(h->device));
-    if (!h->d_P) HIPCHK(hipMalloc(&h->d_P, sizeof(LmhDevParams)));
-    if (!h->P_dev_valid || std::memcmp(&h->P_dev, &h->P, sizeof(LmhDevParams)) != 0) {   // set-up calls changed the block since the last launch
-        HIPCHK(hipStreamSynchronize((hipStream_t)stream));          // an earlier launch on this stream may still read the old copy
-        HIPCHK(hipMemcpy(h->d_P, &h->P, sizeof(LmhDevParams), hipMemcpyHostToDevice));
-        std::memcpy(&h->P_dev, &h->P, sizeof(LmhDevParams)); h->P_dev_valid = true;
+    lmh_handle::Slot &sl = h->slot[h->next_slot++ % lmh_handle::kSlots];
+    if (!sl.d_P) {
+        HIPCHK(hipMalloc(&sl.d_P, sizeof(LmhDevParams)));
+        HIPCHK(hipMalloc(&sl.d_ticket, 2 * sizeof(int)));
+        HIPCHK(hipMemset(sl.d_ticket, 0, 2 * sizeof(int)));
+        HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
-    lmh_launch_rollout(&h->P, h->d_P, d_state, d_out, d_status, d_log, n_ticks, (hipStream_t)stream);
+    if (sl.used) HIPCHK(hipEventSynchronize(sl.done));              // the launch that last used this slot (kSlots launches ago) has left it
+    if (!sl.valid || std::memcmp(&sl.P_dev, &h->P, sizeof(LmhDevParams)) != 0) {   // set-up calls changed the block since this slot was filled
+        std::memcpy(&sl.P_dev, &h->P, sizeof(LmhDevParams));
+        HIPCHK(hipMemcpyAsync(sl.d_P, &sl.P_dev, sizeof(LmhDevParams), hipMemcpyHostToDevice, (hipStream_t)stream));   // stream-ordered in front of the launch; the slot is idle
+        sl.valid = true;
+    }
+    lmh_launch_rollout(&h->P, sl.d_P, sl.d_ticket, d_state, d_out, d_status, d_log, n_ticks, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(sl.done, (hipStream_t)stream));
+    sl.used = true;
     return LMH_OK;
 }
 
@@ -699,16 +726,26 @@ extern "C" int lmh_read_log(const char *path, double *log, uint64_t capacity, ui
 // ---------------------------------------------------------------------------- reference generators on the device
 static int alloc_refs(lmh_handle *h, int n, int n_seg)
 {
-    void **bufs[] = {(void **)&h->d_zx, (void **)&h->d_zy, (void **)&h->d_phase, (void **)&h->d_segs, (void **)&h->d_sos};
-    for (void **b : bufs) if (*b) { HIPCHK(hipFree(*b)); *b = nullptr; }
-    h->n_seg = 0; h->n_samples = 0;
-    HIPCHK(hipMalloc(&h->d_zx, sizeof(double) * (size_t)n));
-    HIPCHK(hipMalloc(&h->d_zy, sizeof(double) * (size_t)n));
-    HIPCHK(hipMalloc(&h->d_phase, (size_t)n));
-    if (n_seg > 0) {
-        HIPCHK(hipMalloc(&h->d_segs, sizeof(double) * LMH_SEG_STRIDE * (size_t)n_seg));
-        HIPCHK(hipMalloc(&h->d_sos, sizeof(uint16_t) * (size_t)n));
+    // allocate the new set first, swap it in, then free the old one: a failed hipMalloc leaves the handle on its previous references
+    // (still consistent with P), never on freed pointers
+    double *zx = nullptr, *zy = nullptr, *segs = nullptr;
+    uint8_t *ph = nullptr;
+    uint16_t *sos = nullptr;
+    hipError_t e = hipMalloc(&zx, sizeof(double) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc(&zy, sizeof(double) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc(&ph, (size_t)n);
+    if (e == hipSuccess && n_seg > 0) e = hipMalloc(&segs, sizeof(double) * LMH_SEG_STRIDE * (size_t)n_seg);
+    if (e == hipSuccess && n_seg > 0) e = hipMalloc(&sos, sizeof(uint16_t) * (size_t)n);
+    if (e != hipSuccess) {
+        void *fresh[] = {zx, zy, ph, segs, sos};
+        for (void *b : fresh) if (b) (void)hipFree(b);
+        return fail(LMH_ERR_HIP, std::string("reference buffers: ") + hipGetErrorString(e));
     }
+    void *old[] = {h->d_zx, h->d_zy, h->d_phase, h->d_segs, h->d_sos};
+    h->d_zx = zx; h->d_zy = zy; h->d_phase = ph; h->d_segs = segs; h->d_sos = sos;
+    h->n_seg = 0; h->n_samples = 0;                                 // the callers set both once the generator kernel has filled the buffers
+    fill_params(h);                                                 // P never points at the freed set
+    for (void *b : old) if (b) (void)hipFree(b);
     return LMH_OK;
 }
 
@@ -716,18 +753,18 @@ extern "C" int lmh_gen_walk(lmh_handle *h, double simulation_time, int num_steps
                             double settle_time, int first_support, double foot_y)
 {
     if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
-    if (num_steps < 1 || num_steps > LMH_GEN_MAX_STEPS) return fail(LMH_ERR_BAD_ARG, "num_steps must be in [1, 126]");
+    if (num_steps < 1 || num_steps > LMH_GEN_MAX_STEPS) return fail(LMH_ERR_BAD_ARG, "num_steps must be in [1, 1022]");
     if (!(time_per_step > 0.0) || !(ds_time >= 0.0) || !(ds_time < time_per_step) || !(settle_time >= 0.0) || !(simulation_time > 0.0))
         return fail(LMH_ERR_BAD_ARG, "need 0 <= ds_time < time_per_step, settle_time >= 0, simulation_time > 0");
     if (first_support != LMH_PHASE_RIGHT && first_support != LMH_PHASE_LEFT) return fail(LMH_ERR_BAD_ARG, "first_support must be LMH_PHASE_RIGHT or LMH_PHASE_LEFT");
-    const int n = (int)((simulation_time + 0.5) / h->cfg.dt);       // zmpGeneration.cpp:41
+    const int n = (int)((simulation_time + 0.5) / h->mpc_dt);       // zmpGeneration.cpp:41
     if (n < 1) return fail(LMH_ERR_BAD_ARG, "no samples");
     HIPCHK(hipSetDevice(h->device));
     const int n_seg = 2 * num_steps + 2;
     int rc = alloc_refs(h, n, n_seg);
     if (rc != LMH_OK) return rc;
     LmhWalkSpec W;
-    W.time_step = h->cfg.dt; W.time_per_step = time_per_step; W.ds_time = ds_time; W.step_height = step_height; W.settle_time = settle_time; W.foot_y = foot_y;
+    W.time_step = h->mpc_dt; W.time_per_step = time_per_step; W.ds_time = ds_time; W.step_height = step_height; W.settle_time = settle_time; W.foot_y = foot_y;
     W.n_samples = n; W.num_steps = num_steps; W.first_support = first_support; W.pad = 0;
     lmh_launch_gen_walk(&W, h->d_zx, h->d_zy, h->d_phase, h->d_segs, h->d_sos, nullptr);
     HIPCHK(hipGetLastError());
@@ -741,12 +778,12 @@ extern "C" int lmh_gen_jump(lmh_handle *h, double simulation_time, double stance
 {
     if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
     if (!(stance_time >= 0.0) || !(flight_time >= 0.0) || !(simulation_time > 0.0)) return fail(LMH_ERR_BAD_ARG, "times must be non-negative");
-    const int n = (int)((simulation_time + 0.5) / h->cfg.dt);
+    const int n = (int)((simulation_time + 0.5) / h->mpc_dt);
     if (n < 1) return fail(LMH_ERR_BAD_ARG, "no samples");
     HIPCHK(hipSetDevice(h->device));
     int rc = alloc_refs(h, n, 0);
     if (rc != LMH_OK) return rc;
-    lmh_launch_gen_jump(n, h->cfg.dt, stance_time, flight_time, h->d_zx, h->d_zy, h->d_phase, nullptr);
+    lmh_launch_gen_jump(n, h->mpc_dt, stance_time, flight_time, h->d_zx, h->d_zy, h->d_phase, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     h->n_samples = n;

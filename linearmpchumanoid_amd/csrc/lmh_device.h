@@ -33,7 +33,8 @@ struct LmhDevParams {
     int32_t bpp_max;            // block-pivoting rounds before the Lawson-Hanson pass (< 0: Lawson-Hanson only)
     int32_t plant;              // 1: compliant-contact plant driven by the torques (lmh_config.plant)
     // ---- scalars (reference literals, see include/lmh.h lmh_config)
-    double dt;
+    double dt;                  // control step (RK4 step of the fused rollout, Clock::step)
+    double mpc_dt;              // MPC sample time: k = int(t / mpc_dt), sample period of the reference arrays (lmh_config.mpc_dt; = dt when that is 0)
     double kp_joints, kd_joints, kp_mom, kd_mom, kp_feet, kd_feet;
     double w_com_lin, w_com_ang, w_base_pos, w_base_ang, w_joints, w_force, w_foot;
     double eps_coeff;
@@ -47,7 +48,7 @@ struct LmhDevParams {
 };
 
 // walking-plan generator (lmh_gen_walk): arguments of the device kernel
-#define LMH_GEN_MAX_STEPS 126
+#define LMH_GEN_MAX_STEPS 1022
 struct LmhWalkSpec {
     double time_step, time_per_step, ds_time, step_height, settle_time, foot_y;
     int32_t n_samples, num_steps, first_support, pad;

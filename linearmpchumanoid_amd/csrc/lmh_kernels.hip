@@ -863,13 +863,17 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
 
 // Dynamics::computeC (gravity / no gravity) + computeJpqpFrame(7),(14): forward and backward
 // Newton-Euler with qdd = 0 on the STALE velocity (Dynamics.cpp:29-60,124-200).
-template <typename R>
+// PLANT = true is the build-defined plant's own pass (lmh_config.plant): the same recursion on the CURRENT velocity (P_VHN), result
+// C(q, v) with gravity into P_VHS (the stale base-frame velocity is dead once the controller's pass has run); P_C, P_CG and P_JPQP are
+// left alone -- the controller's terms keep the reference's stale-velocity semantics.
+template <typename R, bool PLANT = false>
 __device__ __forceinline__ void phase_newton_euler(LV<R> L)
 {
     const int lane = LANE;
+    constexpr int VSRC = PLANT ? (int)P_VHN : (int)P_VHS;
     // base: vel0 = vhat[0:6]; accg0 = X0 * [0 0 0 0 0 9.81]; acc00 = 0
     if (lane < 6) {
-        L[A_VEL + lane] = L[P_VHS + lane];
+        L[A_VEL + lane] = L[VSRC + lane];
         const R g[6] = {0, 0, 0, 0, 0, 9.81};
         L[A_ACCG + lane] = x_mot<R>(L + A_XE, L + A_XB, g, lane);
         L[A_ACC0 + lane] = 0.0;
@@ -893,7 +897,7 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
             const int iv = base + ((d < nact) ? d : 0);
             const int pv = (d == 0) ? 0 : iv - 1;
             R vval = x_mot<R>(L + A_XE + 9 * iv, L + A_XB + 9 * iv, L + A_VEL + 6 * pv, k);
-            const R qdv = L[P_VHS + 5 + iv - adj];
+            const R qdv = L[VSRC + 5 + iv - adj];
             vval += (k == 2) ? qdv : 0.0;
             // ---- acceleration, depth index d-1
             const int e = d - 1;
@@ -901,7 +905,7 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
             const int pa = (e <= 0) ? 0 : ia - 1;
             R aval = x_mot<R>(L + A_XE + 9 * ia, L + A_XB + 9 * ia, L + abase + 6 * pa, k);
             const LV<R> vi = L + A_VEL + 6 * ia;
-            const R qda = L[P_VHS + 5 + ia - adj];
+            const R qda = L[VSRC + 5 + ia - adj];
             // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
             const R cs = cs_sg * (R)vi[cs_ix];                     // one load: (index, sign) derived once per pass
             aval += (e < nact) ? cs * qda : 0.0;
@@ -969,10 +973,11 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
             R acc = L[(w2 ? A_F0 : A_FG) + k2];
 #pragma unroll
             for (int cc = 4; cc >= 0; cc--) acc += L[A_VEL + 12 * cc + 6 * w2 + k2];
-            if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc;
+            if constexpr (PLANT) { if (w2 == 0) L[P_VHS + k2] = acc; }
+            else { if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc; }
         }
-        if (lane >= 16 && lane < 40) L[P_C + 6 + (lane - 16)] = L[A_FG + 6 * f_jframe(lane - 16) + 2];
-        if (lane >= 40 && lane < 52) {                             // Jpqp = blkdiag(R,R) acc0[sole]
+        if (lane >= 16 && lane < 40) L[(PLANT ? (int)P_VHS : (int)P_C) + 6 + (lane - 16)] = L[A_FG + 6 * f_jframe(lane - 16) + 2];
+        if (!PLANT && lane >= 40 && lane < 52) {                   // Jpqp = blkdiag(R,R) acc0[sole]
             const int foot = (lane - 40) / 6, k2 = (lane - 40) % 6, r = k2 % 3, o = (k2 / 3) * 3;
             const LV<R> T = L + P_TB + 12 * (1 + foot), a = L + A_ACC0 + 6 * (foot ? 14 : 7);
             L[P_JPQP + 6 * foot + k2] = T[4 * r] * a[o] + T[4 * r + 1] * a[o + 1] + T[4 * r + 2] * a[o + 2];
@@ -1204,7 +1209,7 @@ struct RefPrefetch { int k; double zx, zy, xs; int ph, seg; };
 __device__ __forceinline__ RefPrefetch prefetch_refs(const LmhDevParams &P, int inst, double t)
 {
     RefPrefetch r;
-    r.k = (int)(t / P.dt);                                         // mpcLinearPendulum.cpp:92 (fp64, same op order)
+    r.k = (int)(t / P.mpc_dt);                                     // mpcLinearPendulum.cpp:92 (fp64, same op order; dt_ = the Mpc3dLip ctor's dt)
     int kk = r.k + LANE;
     kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
     r.zx = P.zmpx[kk]; r.zy = P.zmpy[kk];
@@ -2695,9 +2700,12 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
 }
 
 // ---- build-defined plant (lmh_config.plant): forward dynamics driven by the torques the WBC returns, with a spring-damper
-// contact at the sole vertices.  With tau = (M a + C - J'w)[6:30] and the floating-base rows of the QP, S'tau - C = M a - J'w, so
-//     M qdd_plant = S'tau + J'w_c - C   <=>   qdd_plant = a + M^-1 J'(w_c - w):
-// the plant's acceleration is the controller's plus the response to the contact-wrench error.  M = [Ic0 F2; F2' H] with H block diagonal
+// contact at the sole vertices.  The controller's bias C' = C(q, v_prev) belongs to the PREVIOUS call's velocity (controller.cpp:56 runs
+// before :59); the plant's belongs to the state being integrated, C = C(q, v) (second Newton-Euler pass, phase_newton_euler<R, true>).
+// With tau = (M a + C' - J'w)[6:30] and the floating-base rows of the QP, S'tau = M a + C' - J'w, so
+//     M qdd_plant = S'tau + J'w_c - C   <=>   qdd_plant = a + M^-1 (J'(w_c - w) + C' - C):
+// the plant's acceleration is the controller's plus the response to the contact-wrench error and to the lag of the controller's velocity
+// products.  M = [Ic0 F2; F2' H] with H block diagonal
 // per limb (legs 6x6, arms 5x5, head 2x2): the four limb blocks are eliminated at once on the four DPP rows (Gauss-Jordan, 7 right-hand
 // sides [r_l | F2_l']), the 6x6 base Schur complement (not symmetric: the reference's inertia typos) by one more Gauss-Jordan.
 enum { PL_VF = S0 + 0,      // 8 x 6 : r_v x f_v | f_v per vertex
@@ -2746,13 +2754,13 @@ __device__ __forceinline__ void phase_plant(double *L, const LmhDevParams &P)
         L[PL_DW + lane] = wc - L[P_W12 + lane];
     }
     WSYNC();
-    if (lane < 30) {                                               // r = J'(w_c - w): base and leg columns only
+    if (lane < 30) {                                               // r = J'(w_c - w) (base and leg columns only) + C(q, v_prev) - C(q, v)
         double r = 0.0;
         if (lane < 18) {
 #pragma unroll
             for (int row = 0; row < 12; row++) r += jdense(L, row, lane) * L[PL_DW + row];
         }
-        L[PL_R + lane] = r;
+        L[PL_R + lane] = r + (L[P_C + lane] - L[P_VHS + lane]);    // P_VHS: the plant's own Newton-Euler pass at the current velocity
     }
     WSYNC();
     {   // limb blocks: DPP row dr = limb (RL, LL, RA, LA), lane l16 < 6 = joint of the limb (arms: a unit row pads 5 -> 6)
@@ -2910,14 +2918,21 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         for (int e = LANE; e < 84; e += 64) dbg[588 + e] = L[A_XP + e];
     }
     STAMP(3);
+    const bool plant = P.plant != 0;                               // wave-uniform
     if constexpr (NW == 1) {
         phase_newton_euler<R>(L);
+        if (plant) phase_newton_euler<R, true>(L);                 // the plant's velocity products at the CURRENT velocity (before CRBA reuses the scratch)
         STAMP(4);
         phase_crba<R>(L);
         STAMP(5);
         phase_jacobian<R>(L);
     } else {
-        if (wid == 0) { phase_newton_euler<R>(L); STAMP(4); phase_jacobian<R>(L); }    // LDS regions of the three are disjoint
+        if (wid == 0) {                                            // LDS regions of the three are disjoint
+            phase_newton_euler<R>(L);
+            if (plant) phase_newton_euler<R, true>(L);
+            STAMP(4);
+            phase_jacobian<R>(L);
+        }
         else phase_crba<R>(L);
         STAMP(5);                                                  // per wave: end of its share of the tree phases
     }
@@ -2934,7 +2949,6 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     STAMP(7);
     flags |= phase_qp<NW, QF32>(L, P, ph, wid, Fmask, iters_out, dbg);
     STAMP(8);
-    const bool plant = P.plant != 0;                               // wave-uniform
     if (plant && (NW == 1 || wid == 0)) phase_plant(L, P);         // the torques drive a plant instead of being thrown away (main.cpp:118-121)
     if constexpr (NW == 1) { phase_outputs_tau(L); phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); }
     else { if (wid == 0) phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); else phase_outputs_tau(L); }
@@ -3069,7 +3083,7 @@ template <typename R, bool QF32 = false>
 #endif
 #endif
 __global__ void __launch_bounds__(LMH_ROLLOUT_THREADS) LMH_ROLLOUT_ATTR
-lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, double *state, double *out, int32_t *status, double *log, int n_ticks)
+lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket, double *state, double *out, int32_t *status, double *log, int n_ticks)
 {
     // The parameter block is read through a pointer that is made opaque once per evaluation (params_of): hoisting its ~70 scalars out
     // of the tick loop pins them in SGPRs for the whole launch (round 1: 189 SGPR + 16 VGPR spills, 60 B of scratch per lane that reached
@@ -3079,7 +3093,14 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, 
     // One workgroup runs several robots one after the other (grid = the number of workgroups the chip holds at once, lmh_launch_rollout):
     // when the hardware dispatcher refills the chip from a longer grid, throughput drops by ~15 % (measured: 1024 robots 4.1 ms per launch,
     // 2048 robots 11.4 ms, 4096 robots 19.2 ms for the same 40 ticks); looping inside the resident workgroups keeps the first round's placement.
-    for (int inst = blockIdx.x; inst < P.n_instances; inst += gridDim.x) {      // workgroup-uniform
+    // The first robot of a workgroup is its block index; every further one is drawn from a global ticket (ticket[0], one atomicAdd per
+    // robot): a workgroup whose robots finish early (fewer QP rounds) takes the next one instead of idling behind a static stride, and the
+    // launch ends when the queue is empty.  Which workgroup runs a robot has no influence on its result (all per-robot state is re-read).
+    // The last workgroup to leave (ticket[1] counts them) zeroes both words for the next launch on this slot.
+    __shared__ int s_next;
+    const int n_inst = P.n_instances;
+    int inst = blockIdx.x;
+    while (inst < n_inst) {                                        // workgroup-uniform
     const int lane = LANE;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double *st = state + (size_t)LMH_STATE_STRIDE * inst;
@@ -3173,7 +3194,14 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, LmhDevParams Pv_unused, 
             s[0] = k; s[1] = itmax; s[2] = flags; s[3] = (int32_t)(~F);
         }
     }
-    }                                                              // next robot of this workgroup
+    if (threadIdx.x == 0) s_next = (int)gridDim.x + atomicAdd(&ticket[0], 1);
+    __syncthreads();                                               // also: every lane is done with this robot's LDS image
+    inst = __builtin_amdgcn_readfirstlane(s_next);
+    }                                                              // next robot of this workgroup (the next write of s_next is many barriers away)
+    if (threadIdx.x == 0) {                                        // every draw of this workgroup precedes this increment: the last one to leave resets the slot
+        __threadfence();
+        if (atomicAdd(&ticket[1], 1) == (int)gridDim.x - 1) { ticket[0] = 0; ticket[1] = 0; __threadfence(); }
+    }
 }
 
 // Robot::Robot model preparation (Robot.cpp:14-22) + Dynamics::spatialInertiaMatrix pieces
@@ -3574,23 +3602,29 @@ extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *ou
 // Workgroups the device holds at once: LDS admits four robots per CU (40 KB each of 160 KB).
 static int rollout_resident_groups()
 {
-    static int cached = 0;
-    if (cached == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        int per_cu = 4;
-        if (const char *e = getenv("LMH_ROLLOUT_GROUPS_PER_CU")) { const int v = atoi(e); if (v > 0) per_cu = v; }    // experiments only; read once
-        cached = cus * per_cu;
+    static int cached[64] = {0};                                   // per device index: a process may drive GPUs with different CU counts
+    static int per_cu = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (per_cu == 0) {
+            per_cu = 4;
+            if (const char *e = getenv("LMH_ROLLOUT_GROUPS_PER_CU")) { const int v = atoi(e); if (v > 0) per_cu = v; }    // experiments only; read once
+        }
+        cached[dev] = cus * per_cu;
     }
-    return cached;
+    return cached[dev];
 }
-extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
+// d_ticket: two zero-initialised ints of device memory owned by this launch until it completes (robot queue + departures, see the kernel)
+extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, int *d_ticket, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
 {
     const int slots = rollout_resident_groups();
     const dim3 grid((unsigned)((P->n_instances < slots) ? P->n_instances : slots));
-    if (P->precision == 2) hipLaunchKernelGGL((lmh_rollout_kernel<float, true>), grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
-    else if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
-    else hipLaunchKernelGGL(lmh_rollout_kernel<double>, grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, *P, state, out, status, log, n_ticks);
+    if (P->precision == 2) hipLaunchKernelGGL((lmh_rollout_kernel<float, true>), grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, d_ticket, state, out, status, log, n_ticks);
+    else if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, d_ticket, state, out, status, log, n_ticks);
+    else hipLaunchKernelGGL(lmh_rollout_kernel<double>, grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, d_ticket, state, out, status, log, n_ticks);
 }
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s)
 {

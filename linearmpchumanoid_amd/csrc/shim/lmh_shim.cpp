@@ -163,7 +163,9 @@ Controller::Controller(Robot &robot, Mpc3dLip &mpc, ZMP &zmp, std::vector<Eigen:
     std::cout << ", " << robot_.getCoM()(1) << ", " << robot_.getCoM()(2) << std::endl << std::endl;
     lmh_config cfg;
     lmh_config_default(&cfg);
-    cfg.dt = mpc.getDt(); cfg.time_horizon = mpc.getTimeHorizon(); cfg.z_com = mpc.getZCom();
+    // Mpc3dLip's dt is the MPC sample time; the Clock's step never reaches Controller (the caller's rk4Step integrates on the host), so
+    // the control step of the handle is only a placeholder here and equals it
+    cfg.dt = mpc.getDt(); cfg.mpc_dt = mpc.getDt(); cfg.time_horizon = mpc.getTimeHorizon(); cfg.z_com = mpc.getZCom();
     cfg.alpha = mpc.getAlpha(); cfg.beta = mpc.getBeta();
     cfg.warm_start = 0;                                             // reference: cold start every call (controller.cpp:467)
     if (lmh_create(&cfg, 1, 0, &h_) != LMH_OK) die("lmh_create");

@@ -108,8 +108,10 @@ typedef struct {
     double xscale;
     int wbc_calls_per_eval;     /* 1 (result-neutral default) or 2 (apps/offline/main.cpp:103-105) */
     /* build-defined plant: 0 = the reference's loop, which integrates the controller's own acceleration
-     * (apps/offline/main.cpp:118-121); 1 = forward dynamics M qdd = S'tau + J'w_contact - C driven by the torques the WBC returns,
-     * with a spring-damper contact at the four vertices of each sole (Robot.cpp:38-42) against the plane z = 0 */
+     * (apps/offline/main.cpp:118-121); 1 = forward dynamics M qdd = S'tau + J'w_contact - C(q, v) driven by the torques the WBC returns,
+     * with a spring-damper contact at the four vertices of each sole (Robot.cpp:38-42) against the plane z = 0.  C(q, v) is evaluated at
+     * the velocity of the state being integrated (a second Dynamics::computeC pass after controller.cpp:59), NOT the controller's own C,
+     * which the reference evaluates with the previous call's velocity (controller.cpp:56 before :59) */
     int plant;
     double contact_k, contact_d, contact_dt, contact_mu;   /* normal stiffness [N/m], normal / tangential damping [N s/m], friction */
 } orc_controller;
@@ -154,6 +156,7 @@ extern const int orc_act[ORC_NF];                                     /* Robot.c
 
 /* ---- dynamics / kinematics ---- */
 void orc_dynamics_compute_all(orc_dynamics *d, const orc_robot *r);   /* Dynamics.cpp:202-216 */
+void orc_dynamics_bias_now(const orc_dynamics *d, const orc_robot *r, double C[ORC_NQ]); /* Dynamics.cpp:29-60 at the CURRENT Robot::v_ (plant only) */
 void orc_feet_jacobian(const orc_robot *r, double *JFeet /*12x30*/);  /* invKinematics.cpp:72-149 */
 int  orc_ik_compute(orc_robot *r, const double *desOp);               /* invKinematics.cpp:27-52 */
 void orc_ik_desired_op(const orc_robot *r, const double *Rf, const double *Lf,

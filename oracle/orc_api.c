@@ -294,6 +294,7 @@ void orc_sys_get_gains(void *h, double *g)
 typedef struct {
     int B, nticks, wbc_calls, n_zmp, n_seg;
     double dt, t0, horizonT;
+    double mpc_dt;                   /* Mpc3dLip / ZMP sample time (apps/offline/main.cpp:21,39); the Clock's step is dt (:18) */
     double *states;                  /* [B][60] in/out */
     double *out;                     /* [B][36] or NULL */
     const double *zx, *zy;           /* [n_zmp] */
@@ -315,7 +316,7 @@ static void *batch_ex_worker(void *p)
     for (int i = a->begin; i < a->end; i++) {
         if (!b || s->raw) {                                       /* a randomised model needs its own Robot (Robot.cpp:14-22) */
             if (b) orc_sys_destroy(b);
-            b = (orc_box *)orc_sys_create_model(1.0, s->dt, s->horizonT, 0, s->raw ? s->raw + (size_t)i * ORC_NF * 13 : NULL);
+            b = (orc_box *)orc_sys_create_model(1.0, s->mpc_dt, s->horizonT, 0, s->raw ? s->raw + (size_t)i * ORC_NF * 13 : NULL);
             orc_sys_set_wbc_calls(b, s->wbc_calls, s->wbc_calls > 1);
             orc_controller_set_refs(&b->sys.ctl, s->n_zmp, s->zx, s->zy, s->phase);
         }
@@ -336,11 +337,11 @@ static void *batch_ex_worker(void *p)
 double orc_batch_rollout_ex(int B, double *states, double *out, double t0, double dt, int nticks, double horizonT,
                             int n_zmp, const double *zx, const double *zy, const unsigned char *phase,
                             int n_seg, const double *segs, const unsigned short *sos, const double *xscale,
-                            int n_zcom, const double *zcom, const double *raw, int nthreads, int wbc_calls)
+                            int n_zcom, const double *zcom, const double *raw, int nthreads, int wbc_calls, double mpc_dt /* <= 0: dt */)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > B) nthreads = B;
-    batch_ex_shared s = {B, nticks, wbc_calls, n_zmp, n_seg, dt, t0, horizonT, states, out, zx, zy, phase, segs, sos, xscale, zcom, n_zcom, raw};
+    batch_ex_shared s = {B, nticks, wbc_calls, n_zmp, n_seg, dt, t0, horizonT, (mpc_dt > 0.0) ? mpc_dt : dt, states, out, zx, zy, phase, segs, sos, xscale, zcom, n_zcom, raw};
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
     batch_ex_arg *args = (batch_ex_arg *)malloc(sizeof(batch_ex_arg) * (size_t)nthreads);
     struct timespec a, b;

@@ -325,18 +325,21 @@ void orc_contact_wrench(const orc_system *s, const double *JFeet, double w[12], 
     }
 }
 
-/* plant acceleration: M a = S'tau + J'w_contact - C in the WBC's coordinates (base twist in the base frame, [ang; lin]), then back to
- * the world frame like controller.cpp:143-147.  M, C, J are the terms the controller evaluated in this call. */
+/* plant acceleration: M a = S'tau + J'w_contact - C(q, v) in the WBC's coordinates (base twist in the base frame, [ang; lin]), then back to
+ * the world frame like controller.cpp:143-147.  M and J are the terms the controller evaluated in this call; the velocity products are
+ * re-evaluated at the CURRENT velocity (Robot::v_ after controller.cpp:59): the controller's own C belongs to the previous call's
+ * velocity (:56 runs before :59) and would let the momentum of the plant drift. */
 static void plant_acceleration(orc_system *s, const orc_eval *out, double qpp[ORC_NQ])
 {
     const int n = ORC_NQ;
     const orc_dynamics *d = &s->dyn;
-    double w[12], rhs[ORC_NQ], a[ORC_NQ], M[ORC_NQ * ORC_NQ];
+    double w[12], rhs[ORC_NQ], a[ORC_NQ], M[ORC_NQ * ORC_NQ], Cnow[ORC_NQ];
     orc_contact_wrench(s, out->JFeet, w, NULL);
+    orc_dynamics_bias_now(d, &s->robot, Cnow);
     for (int i = 0; i < n; i++) {
         double jw = 0.0;
         for (int k = 0; k < 12; k++) jw += out->JFeet[k * n + i] * w[k];
-        rhs[i] = ((i >= 6) ? out->tau[i - 6] : 0.0) + jw - d->C[i];
+        rhs[i] = ((i >= 6) ? out->tau[i - 6] : 0.0) + jw - Cnow[i];
     }
     memcpy(M, d->M, sizeof(M));
     orc_solve_ge(n, M, rhs, a);

@@ -168,6 +168,11 @@ static void compute_jpqp_frame(const orc_dynamics *d, const orc_robot *r, int fr
     }
 }
 
+/* Dynamics::computeC(robot, gravity = true) (:29-60) on whatever Robot::v_ holds NOW.  The controller never calls it at this point; the
+ * build-defined plant does, after Controller::standStep has stored the new velocity (controller.cpp:59), so that its velocity products
+ * belong to the state being integrated and not to the previous call's.  d->I must be current (computeAll of this call). */
+void orc_dynamics_bias_now(const orc_dynamics *d, const orc_robot *r, double C[ORC_NQ]) { compute_C(d, r, 1, C); }
+
 void orc_dynamics_compute_all(orc_dynamics *d, const orc_robot *r)   /* :202-216 */
 {
     all_spatial_inertias(d, r);

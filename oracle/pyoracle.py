@@ -54,7 +54,11 @@ def _f64(*shape):
 
 
 class Oracle:
-    """One robot + controller, mirroring the object graph of apps/offline/main.cpp."""
+    """One robot + controller, mirroring the object graph of apps/offline/main.cpp.
+
+    `dt` is what main.cpp hands to ZMP (:21) and Mpc3dLip (:39): the MPC sample time.  The Clock's step (:18) only enters
+    through rollout(..., dt=...), so a control step different from the MPC sample time is rollout(dt=control_dt) on an
+    Oracle(dt=mpc_dt)."""
 
     def __init__(self, sim_time=5.0, dt=0.01, horizon_time=0.5, do_ik=True, raw_links=None):
         L = lib()
@@ -241,9 +245,11 @@ def batch_rollout(states, prev_v, t0, dt, nticks, sim_time, horizon_time, zcom, 
 
 
 def batch_rollout_ex(states, t0, dt, nticks, horizon_time, zmp_x, zmp_y, phase=None, segs=None, seg_of_sample=None,
-                     xscale=None, zcom=0.26, raw_links=None, nthreads=1, wbc_calls=1, lib_override=None):
+                     xscale=None, zcom=0.26, raw_links=None, nthreads=1, wbc_calls=1, lib_override=None, mpc_dt=None):
     """CPU baseline, general form: B independent closed loops with caller-supplied references (walking / jumping
-    plans), per-instance step length, LIPM height and (optionally) raw link tables.  Returns (seconds, states, out[B,36])."""
+    plans), per-instance step length, LIPM height and (optionally) raw link tables.  dt is the Clock's step (RK4 step),
+    mpc_dt the Mpc3dLip / ZMP sample time (apps/offline/main.cpp:18 vs :21,39; None = dt), horizon_time = N mpc_dt.
+    Returns (seconds, states, out[B,36])."""
     L = lib_override if lib_override is not None else lib()
     st = np.ascontiguousarray(states, dtype=np.float64).copy()
     B = st.shape[0]
@@ -261,5 +267,5 @@ def batch_rollout_ex(states, t0, dt, nticks, horizon_time, zmp_x, zmp_y, phase=N
     fn.restype = C.c_double
     sec = fn(C.c_int(B), _p(st), _p(out), C.c_double(t0), C.c_double(dt), C.c_int(nticks), C.c_double(horizon_time),
              C.c_int(len(zx)), _p(zx), _p(zy), _p(ph), C.c_int(0 if sg is None else sg.shape[0]), _p(sg), _p(so), _p(xs),
-             C.c_int(len(zc)), _p(zc), _p(raw), C.c_int(nthreads), C.c_int(wbc_calls))
+             C.c_int(len(zc)), _p(zc), _p(raw), C.c_int(nthreads), C.c_int(wbc_calls), C.c_double(0.0 if mpc_dt is None else mpc_dt))
     return sec, st, out

@@ -29,7 +29,7 @@ for row in csv.DictReader(open(stats)):
         avg_ns, calls = float(row["AverageNs"]), int(row["Calls"])
 pmc = {}
 meta = {}
-for sub in ("fetch", "write", "sq", "sq2", "grbm"):
+for sub in ("fetch", "write", "sq", "sq2", "f64", "ins", "grbm"):
     try:
         f = find(sub, "counter_collection.csv")
     except SystemExit:
@@ -46,7 +46,23 @@ for sub in ("fetch", "write", "sq", "sq2", "grbm"):
         pmc[name] = sum(v for _, v in vals) / max(1, len(vals))
 evals = B * ticks * 4
 g = lambda k: pmc.get(k, float("nan"))
+# counted fp64 work: the SQ counts wave-level instructions per class; one instruction occupies 64 lane slots whatever the EXEC mask, so
+# x 64 is the lane CAPACITY the kernel spent on fp64 arithmetic -- an upper bound of the useful flop (lanes switched off by EXEC, and
+# lanes computing padding / safe-address dummies, are included).  FMA = 2 flop; one MFMA_MOPS_F64 unit = 512 flop.
+_f64 = [pmc.get(k) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
+counted = None
+if all(v is not None for v in _f64) and "SQ_INSTS_VALU_MFMA_MOPS_F64" in pmc:
+    counted = (64.0 * (_f64[0] + _f64[1] + 2.0 * _f64[2] + _f64[3]) + 512.0 * pmc["SQ_INSTS_VALU_MFMA_MOPS_F64"]) / evals
 derived = {
+    "counted_fp64_flop_per_eval": counted,
+    "counted_fp64_flop_note": None if counted is None else
+        "64 lanes x (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 FMA_F64 + TRANS_F64) + 512 x SQ_INSTS_VALU_MFMA_MOPS_F64 per evaluation: lane capacity of the fp64 "
+        "instructions issued (EXEC-masked and padding lanes included), an upper bound of the useful arithmetic",
+    "f64_valu_insts_per_eval": None if counted is None else {"add": _f64[0] / evals, "mul": _f64[1] / evals, "fma": _f64[2] / evals, "trans": _f64[3] / evals},
+    "other_valu_insts_per_eval": {k[len("SQ_INSTS_VALU_"):].lower(): pmc[k] / evals for k in ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT",
+                                  "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32") if k in pmc},
+    "smem_insts_per_eval": pmc["SQ_INSTS_SMEM"] / evals if "SQ_INSTS_SMEM" in pmc else None,
+    "branch_insts_per_eval": pmc["SQ_INSTS_BRANCH"] / evals if "SQ_INSTS_BRANCH" in pmc else None,
     "valu_insts_per_eval": g("SQ_INSTS_VALU") / evals, "salu_insts_per_eval": g("SQ_INSTS_SALU") / evals,
     "lds_insts_per_eval": g("SQ_INSTS_LDS") / evals, "mfma_f64_mops_per_eval": g("SQ_INSTS_VALU_MFMA_MOPS_F64") / evals,
     "wave_cycles_per_eval": g("SQ_WAVE_CYCLES") / evals,
@@ -61,7 +77,7 @@ derived = {
             "access width here is 8 B/lane (uncalibrated), so the read side is bracketed by [raw, 2x raw]",
 }
 out = {
-    "command": "scripts/profile_rollout.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline [config args] (the default bench command); PMC: separate --pmc passes, --steps 5 --warmup 1",
+    "command": "scripts/profile_rollout.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline [config args] (the default bench command); PMC: separate --pmc passes, --steps 3 --warmup 1",
     "kernel": KERNEL, "dispatch": meta, "workload": f"{B} instances x {ticks} RK4 ticks per launch",
     "avg_launch_ns": avg_ns, "calls": calls, "pmc_per_launch": pmc, "derived": derived,
 }

@@ -13,6 +13,40 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / scale)
 
 
+def vec_err(a, b):
+    """max|a - b| / max|b| of the SAME vector (north_star / SURVEY 8d); inf when the reference is all-zero and the vectors differ."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    d = float(np.abs(a - b).max()) if a.size else 0.0
+    den = float(np.abs(b).max()) if b.size else 0.0
+    if den == 0.0:
+        return 0.0 if d == 0.0 else float("inf")
+    return d / den
+
+
+def close_on(a, b, tol, scale):
+    """max|a - b| <= tol * scale with an EXPLICIT physical scale: for quantities that are small differences of larger ingredients
+    (velocity products at rest, PD references of a robot standing on its references), where max|b| of the vector itself is round-off of
+    those ingredients.  The caller names the ingredient scale; there is no implicit 1.0."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return bool(np.abs(a - b).max() <= tol * float(scale))
+
+
+def close(a, b, tol=TOL_REL, scale=None):
+    """The parity rule of north_star / SURVEY 8d: max|a - b| <= tol * max|b| of the SAME vector -- relative, with no absolute 1.0 in
+    the denominator.  `scale` (optional) is the max-abs entry of the quantity SET the vector belongs to (e.g. the robot's weight for
+    a contact-force vector that is identically zero in flight): it adds SURVEY's absolute floor TOL_FLOOR * scale = 1e-9 * scale to the
+    allowed error.  Without it an all-zero reference demands identical vectors.  NaN anywhere fails."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    d = np.abs(a - b).max()
+    allowed = tol * np.abs(b).max()
+    if scale is not None:
+        allowed = max(allowed, TOL_FLOOR * float(scale))
+    return bool(d <= allowed)
+
+
+WEIGHT = 5.305 * 9.81    # m g of the nominal NAO [N] (Robot::getMass 5.305 kg): the scale of the contact-force set
+
+
 def perturbed_velocities(B, seed=20260001):
     """BASELINE config 2 perturbation: dq[0:2] ~ U(-0.3,0.3) m/s, dq[6:30] ~ N(0,0.05^2) rad/s."""
     v = np.zeros((B, 30))

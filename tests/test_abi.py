@@ -98,3 +98,21 @@ int main(void) {{
     out = subprocess.check_output([str(exe)]).decode().split()       # lmh_config_default touches no device
     assert int(out[0]) == C.sizeof(capi.LmhConfig)
     assert int(out[1]) == capi.PRECISION_FP64 and float(out[2]) == 0.01 and float(out[3]) == 1e-8
+
+
+def test_config_carries_the_mpc_sample_time(hip_lib):
+    """lmh_config.mpc_dt (0 = dt) is the last field of the record; N = int(time_horizon / mpc_dt) is validated at create time even
+    without a device (bad values are refused before the device is looked for)."""
+    import ctypes as C
+    from linearmpchumanoid_amd.capi import LmhConfig
+    from linearmpchumanoid_amd.controller import default_config
+    assert LmhConfig._fields_[-1][0] == "mpc_dt" and C.sizeof(LmhConfig) == 8 * 21 + 4 * 6 + 8 * 5
+    cfg = default_config()
+    assert cfg.mpc_dt == 0.0
+    h = C.c_void_p()
+    bad = default_config(dt=1e-3, time_horizon=0.32, mpc_dt=-1.0)
+    assert hip_lib.lmh_create(C.byref(bad), 1, 0, C.byref(h)) == -2 and b"mpc_dt" in hip_lib.lmh_last_error()
+    bad = default_config(dt=1e-3, time_horizon=0.7, mpc_dt=1e-2)         # N = 70 > 64
+    assert hip_lib.lmh_create(C.byref(bad), 1, 0, C.byref(h)) == -2 and b"mpc_dt" in hip_lib.lmh_last_error()
+    ok = default_config(dt=1e-3, time_horizon=0.7)                        # mpc_dt = dt: N = 700 is refused the same way
+    assert hip_lib.lmh_create(C.byref(ok), 1, 0, C.byref(h)) == -2

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import TOL_REL, dense_terms_from_debug, oracle_system, perturbed_velocities, rel_err
+from helpers import TOL_REL, WEIGHT, close, close_on, dense_terms_from_debug, oracle_system, perturbed_velocities, rel_err
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -70,9 +70,11 @@ def test_stage_parity_single_evaluation(cfg2):
         # velocity-product terms are differences of O(50) quantities: compare on that scale
         assert np.abs(d["Cg6"] - t["Cg"][:6]).max() < 1e-11 * np.abs(t["C"]).max()
         assert np.abs(d["AGpqp"] - t["AGpqp"]).max() < 1e-11 * np.abs(t["C"]).max()
-        assert np.abs(d["Jpqp"] - t["Jpqp"]).max() < 1e-11 * max(1.0, np.abs(t["Jpqp"]).max())
-        assert np.abs(d["footAccRef"] - qp["footAccRef"]).max() < 1e-10 * max(1.0, np.abs(qp["footAccRef"]).max())
-        assert np.abs(d["mpc"][:2] - qp["u0"]).max() < 1e-11 * max(1.0, np.abs(qp["u0"]).max())
+        assert close_on(d["Jpqp"], t["Jpqp"], 1e-11, np.abs(t["C"]).max())
+        # PD references of a robot standing on its references: differences of kp * position (500 x 0.05 m) and kd * velocity terms
+        assert close_on(d["footAccRef"], qp["footAccRef"], 1e-10, 500.0 * 0.05 + np.abs(qp["footAccRef"]).max())
+        # u0 = -K (Px x - z): sum of K_i x_com terms, |K|_1 |x| ~ (g / z_c) |x_com|
+        assert close_on(d["mpc"][:2], qp["u0"], 1e-11, 9.81 / 0.26 * 0.05 + np.abs(qp["u0"]).max())
         assert rel_err(d["a"], qp["x"][:30]) < 1e-8
         assert rel_err(out[i, :24], e["tau"]) < TOL_REL and rel_err(out[i, 24:36], e["f"]) < TOL_REL
         assert rel_err(out[i, 36:66], e["qpp"]) < TOL_REL
@@ -112,7 +114,7 @@ def test_rollout_parity_config2_fixture():
         stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
         for i in range(B):
             assert status[i, 0] == int(g["k"][i][-1]) and status[i, 2] == 0
-            assert np.abs(stn[i, :60] - g["state"][i]).max() < 1e-8 * max(1.0, np.abs(g["state"][i]).max())
+            assert close(stn[i, :60], g["state"][i], 1e-8)
             for tk in range(nt):
                 assert rel_err(log[tk, i, :24], g["log"][i, tk, :24]) < TOL_REL, (warm, i, tk)
                 assert rel_err(log[tk, i, 24:], g["log"][i, tk, 24:]) < TOL_REL, (warm, i, tk)
@@ -174,7 +176,7 @@ def test_support_phases_and_flight(cfg2):
             o.set_refs(zx, zy, np.full(len(zx), ph, dtype=np.uint8))
             e = o.eval(cfg2["q0"], v[i], 0.0)
             assert rel_err(out[i, :24], e["tau"]) < TOL_REL
-            assert np.abs(out[i, 24:36] - e["f"]).max() < TOL_REL * max(1.0, np.abs(e["f"]).max())
+            assert close(out[i, 24:36], e["f"], TOL_REL, scale=WEIGHT)
 
 
 def test_domain_randomised_models(cfg2):
@@ -307,11 +309,11 @@ def test_walking_contact_switching_parity(cfg2):
         o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
         r = o.rollout(np.concatenate([cfg2["q0"], np.zeros(30)]), 0.0, nt, log=True)
         assert status[i, 0] == r["k"][-1]
-        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+        assert close(stn[i, :60], r["state"], 1e-7)
         for tk in range(0, nt, 7):
             ref = r["log"][tk]
-            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
-            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+            assert close(log[tk, i, :24], ref[:24], TOL_REL), (i, tk)
+            assert close(log[tk, i, 24:], ref[24:], TOL_REL, scale=WEIGHT), (i, tk)
             if np.abs(ref[24 + 6:24 + 12]).max() < 1e-9 and np.abs(ref[24:24 + 6]).max() > 1.0:
                 saw_single_support = True
                 assert np.abs(log[tk, i, 24 + 6:]).max() == 0.0     # swing foot carries exactly no force
@@ -344,11 +346,11 @@ def test_jump_schedule_parity_config5_ingredients(cfg2):
         o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
         r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, nt, log=True)
         assert status[i, 0] == r["k"][-1]
-        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+        assert close(stn[i, :60], r["state"], 1e-7)
         for tk in range(nt):
             ref = r["log"][tk]
-            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
-            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+            assert close(log[tk, i, :24], ref[:24], TOL_REL), (i, tk)
+            assert close(log[tk, i, 24:], ref[24:], TOL_REL, scale=WEIGHT), (i, tk)
             if plan["phase"][r["k"][tk]] == 3:                      # k of the logged (stage-4) evaluation
                 flight_ticks += 1
                 assert np.abs(log[tk, i, 24:]).max() == 0.0        # no contact force at all, exactly
@@ -416,11 +418,11 @@ def test_full_size_walking_config3(cfg2):
         o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
         o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
         r = o.rollout(np.concatenate([cfg2["q0"], np.zeros(30)]), 0.0, nt, log=True)
-        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+        assert close(stn[i, :60], r["state"], 1e-7)
         for tk in range(0, nt, 5):
             ref = r["log"][tk]
-            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
-            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+            assert close(log[tk, i, :24], ref[:24], TOL_REL), (i, tk)
+            assert close(log[tk, i, 24:], ref[24:], TOL_REL, scale=WEIGHT), (i, tk)
 
 
 def test_randomised_walking_config4_ingredients(cfg2):
@@ -469,8 +471,8 @@ def test_randomised_walking_config4_ingredients(cfg2):
         assert status[i, 0] == r["k"][-1]
         for tk in range(0, nt, 3):
             ref = r["log"][tk]
-            assert np.abs(log[tk, i, :24] - ref[:24]).max() < TOL_REL * max(1.0, np.abs(ref[:24]).max()), (i, tk)
-            assert np.abs(log[tk, i, 24:] - ref[24:]).max() < TOL_REL * max(1.0, np.abs(ref[24:]).max()), (i, tk)
+            assert close(log[tk, i, :24], ref[:24], TOL_REL), (i, tk)
+            assert close(log[tk, i, 24:], ref[24:], TOL_REL, scale=WEIGHT), (i, tk)
 
 
 def test_arbitrary_warm_start_sets_reach_the_same_minimiser(cfg2):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import TOL_REL, oracle_system, perturbed_velocities, rel_err
+from helpers import TOL_REL, WEIGHT, close, close_on, oracle_system, perturbed_velocities, rel_err, vec_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,11 +27,6 @@ def make_controller(B, dt, th, zcom, **kw):
 def cfg2():
     o = oracle_system(1e-3, 0.016)
     return dict(dt=1e-3, th=0.016, zcom=o.zcom, q0=o.robot()["q"].copy())
-
-
-def close(a, b, tol=TOL_REL):
-    """|a - b| <= tol * max(1, max|b|): relative on the vector scale with an absolute floor for all-zero references"""
-    return np.abs(np.asarray(a) - np.asarray(b)).max() <= tol * max(1.0, np.abs(b).max())
 
 
 # ------------------------------------------------------------------------------- (a) the regime bench.py --config 2 times
@@ -54,8 +49,8 @@ def test_config2_benched_regime_against_oracle(cfg2):
         r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, nt, log=True)
         assert status[i, 0] == r["k"][-1]
         for tk in (99, 199, 249):
-            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
-        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:], scale=WEIGHT), (i, tk)
+        assert close(stn[i, :60], r["state"], 1e-7)
         n_active += int(status[i, 3] != 0)
     assert n_active >= 4                                          # the sampled robots include ones with active friction bounds
 
@@ -91,7 +86,7 @@ def test_non_default_gains_and_weights(cfg2, over):
             o.set_refs(zx, zy, np.full(len(zx), ph, dtype=np.uint8))
             o.set_prev_velocity(vprev[i])
             e = o.eval(cfg2["q0"], v[i], 0.0)
-            assert close(out[i, :24], e["tau"]) and close(out[i, 24:36], e["f"]) and close(out[i, 36:66], e["qpp"]), (ph, i)
+            assert close(out[i, :24], e["tau"]) and close(out[i, 24:36], e["f"], scale=WEIGHT) and close(out[i, 36:66], e["qpp"]), (ph, i)
             if "mu" in over:
                 fx, fy, fz = out[i, 24 + 3:24 + 6]
                 assert abs(fx) <= over["mu"] * fz + 1e-7 and abs(fy) <= over["mu"] * fz + 1e-7
@@ -107,7 +102,7 @@ def test_non_default_gains_and_weights(cfg2, over):
         o.set_gains(**over)
         r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, 25, log=True)
         for tk in range(0, 25, 4):
-            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
+            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:], scale=WEIGHT), (i, tk)
 
 
 # ------------------------------------------------------------------------------- (c) Lawson-Hanson fall-back
@@ -237,12 +232,12 @@ def test_com_velocity_momentum_and_mpc_references_directly(cfg2):
         d = unpack_debug(dbg[i])
         assert status[i, 0] == e["k"] == 123
         assert np.abs(out[i, 66:69] - rb["CoM"]).max() < 1e-12
-        assert np.abs(out[i, 69:72] - rb["comVel"]).max() < 1e-11 * max(1.0, np.abs(rb["comVel"]).max())
-        assert np.abs(d["comVel"] - rb["comVel"]).max() < 1e-11 * max(1.0, np.abs(rb["comVel"]).max())
-        assert np.abs(d["angMom"] - rb["angMom"]).max() < 1e-11 * max(1.0, np.abs(rb["angMom"]).max())
-        assert np.abs(out[i, 72:75] - qp["mpcRef"][:3]).max() < 1e-9 * max(1.0, np.abs(qp["mpcRef"]).max())     # getXRef
-        assert np.abs(out[i, 75:78] - qp["mpcRef"][3:]).max() < 1e-9 * max(1.0, np.abs(qp["mpcRef"]).max())     # getYRef
-        assert np.abs(d["mpc"][:2] - qp["u0"]).max() < 1e-10 * max(1.0, np.abs(qp["u0"]).max())
+        assert close(out[i, 69:72], rb["comVel"], 1e-11)
+        assert close(d["comVel"], rb["comVel"], 1e-11)
+        assert close(d["angMom"], rb["angMom"], 1e-11)
+        assert close_on(out[i, 72:75], qp["mpcRef"][:3], 1e-9, np.abs(qp["mpcRef"]).max())     # getXRef
+        assert close_on(out[i, 75:78], qp["mpcRef"][3:], 1e-9, np.abs(qp["mpcRef"]).max())     # getYRef (y ~ 0: on the scale of the x record)
+        assert close_on(d["mpc"][:2], qp["u0"], 1e-10, 9.81 / 0.26 * 0.05 + np.abs(qp["u0"]).max())
 
 
 # ------------------------------------------------------------------------------- (f) config 4 at one GPU's share
@@ -254,7 +249,7 @@ def test_config4_one_gpu_share_randomised_ik_walking():
     sys.path.insert(0, ROOT)
     import bench
     from oracle.pyoracle import Oracle
-    args = bench.parse(["--config", "4"])
+    args = bench.parse(["--config", "4", "--coupled"])            # mpc_dt = dt, 0.2 s steps (the decoupled form: test_gpu_round3)
     B, nt = args.instances, 480
     ctl = make_controller(B, args.dt, args.horizon * args.dt, 0.26, warm_start=1)
     state, host = bench.build_workload(args, ctl, 0, B, nt)
@@ -282,9 +277,9 @@ def test_config4_one_gpu_share_randomised_ik_walking():
         o.set_refs(host["zmp_x"], host["zmp_y"], host["phase"])
         o.set_segments(host["segs"], host["sos"], xscale=float(host["xscale"][i]))
         r = o.rollout(np.concatenate([o.robot()["q"], np.zeros(30)]), 0.0, nt, log=True)
-        assert np.abs(stn[i, :60] - r["state"]).max() < 1e-7 * max(1.0, np.abs(r["state"]).max())
+        assert close(stn[i, :60], r["state"], 1e-7)
         for tk in range(0, nt, 6):
-            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
+            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:], scale=WEIGHT), (i, tk)
 
 
 # ------------------------------------------------------------------------------- (g) config 5, real schedule
@@ -331,9 +326,9 @@ def test_config5_jump_schedule_full_size():
         assert last >= 550                                          # stance and the whole flight phase are always comparable
         for tk in list(range(0, last, 10)) + [399, 400, 549, min(550, last - 1)]:
             ref = r["log"][tk]
-            assert close(log[tk, i, :24], ref[:24]) and close(log[tk, i, 24:], ref[24:]), (i, tk)
+            assert close(log[tk, i, :24], ref[:24]) and close(log[tk, i, 24:], ref[24:], scale=WEIGHT), (i, tk)
         if last == nt:
-            assert status[i, 2] == 0 and np.abs(stn[i, :60] - r["state"]).max() < 1e-6 * max(1.0, np.abs(r["state"]).max())
+            assert status[i, 2] == 0 and close(stn[i, :60], r["state"], 1e-6)
         checked += 1
     assert checked == 8
 
@@ -371,7 +366,7 @@ def test_walk_generator_kernel_matches_the_host_plan(gait):
                 for der in range(3):
                     pd = np.polynomial.polynomial.Polynomial(cd).deriv(der)(t) if der else np.polynomial.polynomial.polyval(t, cd)
                     phh = np.polynomial.polynomial.Polynomial(ch).deriv(der)(t) if der else np.polynomial.polynomial.polyval(t, ch)
-                    assert np.abs(pd - phh).max() < 1e-12 * max(1.0, np.abs(phh).max()), (ft, ax, der)
+                    assert close(pd, phh, 1e-12), (ft, ax, der)
                 assert np.abs(cd - ch).max() < 1e-11 * np.abs(ch).max()
 
 
@@ -404,15 +399,15 @@ def test_jump_generator_kernel_and_rollout_on_generated_plans(cfg2):
         r = o.rollout(np.concatenate([cfg2["q0"], np.zeros(30)]), 0.0, nt, log=True)
         assert status[i, 0] == r["k"][-1]
         for tk in range(0, nt, 9):
-            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
+            assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:], scale=WEIGHT), (i, tk)
 
 
 # ------------------------------------------------------------------------------- plant
 def test_plant_rollout_parity_and_physics(cfg2):
-    """lmh_config.plant = 1: the RK4 derivative is the forward dynamics M qdd = S'tau + J'w_contact - C driven by the WBC torques, with
-    the spring-damper contact at the sole vertices.  (i) against the oracle's plant (literal dense M solve) over 200 ticks of a
-    standing robot with small velocity perturbations, two contact parameter sets; (ii) physics: the ground carries the weight once the
-    contact has settled; a robot released above the ground falls."""
+    """lmh_config.plant = 1: the RK4 derivative is the forward dynamics M qdd = S'tau + J'w_contact - C(q, v) driven by the WBC torques,
+    with the spring-damper contact at the sole vertices.  (i) against the oracle's plant (literal dense M solve, Dynamics::computeC
+    re-run at the current velocity) over 200 ticks of a standing robot with small velocity perturbations, two contact parameter sets;
+    (ii) physics: the ground carries the weight once the contact has settled."""
     from oracle.pyoracle import Oracle
     dt, th = 1e-3, 0.032
     B, nt = 6, 200
@@ -432,30 +427,14 @@ def test_plant_rollout_parity_and_physics(cfg2):
             o.set_plant(True, k=contact["contact_k"], d=contact["contact_d"], dt=contact["contact_dt"], mu=contact["contact_mu"])
             r = o.rollout(np.concatenate([cfg2["q0"], v[i]]), 0.0, nt, log=True)
             assert status[i, 0] == r["k"][-1]
-            assert np.abs(stn[i, :60] - r["state"]).max() < 1e-6 * max(1.0, np.abs(r["state"]).max()), (i, np.abs(stn[i, :60] - r["state"]).max())
+            assert close(stn[i, :60], r["state"], 1e-6), (i, np.abs(stn[i, :60] - r["state"]).max())
             for tk in range(0, nt, 7):
-                assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:]), (i, tk)
+                assert close(log[tk, i, :24], r["log"][tk][:24]) and close(log[tk, i, 24:], r["log"][tk][24:], scale=WEIGHT), (i, tk)
             if i == 0:                                             # unperturbed robot: after 0.2 s the springs carry m g
                 w, vf = o.contact()
                 assert abs(w[5] + w[11] - o.mass * 9.81) < 0.05 * o.mass * 9.81 and (vf[:, 2] >= 0).all()
-    # free fall: released 0.2 m above the ground, no vertex touches it -> the CoM falls with g whatever the joints do
-    ctl = make_controller(2, dt, th, cfg2["zcom"], warm_start=1, plant=1)
-    ctl.set_refs_stance(2.0, 2)
-    q = cfg2["q0"].copy(); q[2] += 0.2
-    st = ctl.new_state(q, np.zeros(30), t=0.0)
-    out0, s0 = ctl.stand_step(st.clone())
-    c0 = out0.cpu().numpy()[0, 66:69]
-    n = 8
-    ctl.rollout(st, n)
-    out1, s1 = ctl.stand_step(st.clone())
-    torch.cuda.synchronize()
-    o1 = out1.cpu().numpy()[0]
-    # The plant reuses the C the controller evaluated, i.e. with the PREVIOUS call's velocity (controller.cpp:56 before :59).  In the air
-    # nothing resists the ankle torques and the legs whip (40 rad/s after 10 ms, 130 rad/s after 20 ms), so the lagging velocity products
-    # let the momentum drift after ~10 ms; over the first 8 ms the CoM follows the free fall to a few per cent and stays on its vertical.
-    drop, ideal = o1[68] - c0[2], -0.5 * 9.81 * (n * dt) ** 2
-    assert abs(drop - ideal) < 0.06 * abs(ideal), (drop, ideal)
-    assert abs(o1[71] - (-9.81 * n * dt)) < 0.06 * 9.81 * n * dt and np.abs(o1[69:71]).max() < 2e-3
+    # free fall and momentum conservation: see test_gpu_round3.test_plant_free_fall_and_momentum (the plant's velocity products are
+    # evaluated at the current velocity since round 3)
 
 
 # ------------------------------------------------------------------------------- summary kernel, record files, N > 1 entry
@@ -533,6 +512,8 @@ def test_bench_default_line_shape():
     rf = res["roofline"]
     assert rf["bound"] == "fp64-valu" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["hbm"]["unit"] == "GB/s" and rf["kernel_ms"] > 0 and res["instances_flagged"] == 0
+    assert res["config"]["rollout_restarts"] == 0 and res["config"]["mpc_dt"] == 1e-2 and res["timed_region_s"] > 0
+    assert rf["nominal_flop_per_tick"] == 8.0e5 and "counted_flop_per_tick" in rf and "frac_counted" in rf
     cb = res["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["cpu_model"]
     assert cb["parity_vs_gpu_last_tick_max_rel"] < 1e-6

@@ -138,18 +138,29 @@ def _bench_mod():
 
 
 def test_bench_defaults_name_the_largest_single_gpu_config():
-    """python bench.py (N = 1) measures BASELINE configs[2]: 4096 robots, walking, N = 32; --gpus N > 1 one GPU's share of configs[3]."""
+    """python bench.py (N = 1) measures BASELINE configs[2]: 4096 robots, walking, N = 32 x mpc_dt 10 ms, one step = one whole 4 000-tick
+    rollout segment, nothing restarted; --gpus N > 1 one GPU's share of configs[3]; --coupled keeps rounds 1-2's line."""
     b, _ = _bench_mod()
     a = b.parse([])
-    assert (a.config, a.instances, a.horizon, a.gpus) == (3, 4096, 32, 1)
-    assert a.reset_every * a.ticks <= 480                          # the walking loop's valid range (bench.DEFAULTS)
-    assert (a.steps * a.ticks * a.instances) >= 3_000_000           # >= 0.5 s of timed region at ~6 M ticks/s
+    assert (a.config, a.instances, a.horizon, a.gpus, a.ticks, a.mpc_dt, a.reset_every) == (3, 4096, 32, 1, 4000, 1e-2, 0)
+    assert (a.step_time, a.ds_time) == (0.5, 0.2)                   # the reference's default timePerStep (zmpGeneration.hpp:37-38)
+    assert a.horizon * a.mpc_dt >= 0.32 - 1e-12                     # a preview the LIPM loop is stable with
+    assert a.steps * a.ticks * a.instances / 20e6 >= 3.0            # timed region >= 3 s even at 20 M ticks/s
+    d = b.parse(["--steps", "20", "--warmup", "5"])                 # the driver's flags
+    assert d.ticks == 4000 and d.reset_every == 0
     a8 = b.parse(["--gpus", "8"])
-    assert (a8.config, a8.instances) == (4, 4096)
+    assert (a8.config, a8.instances, a8.ticks) == (4, 4096, 4000)
     a2 = b.parse(["--config", "2"])
-    assert (a2.instances, a2.horizon, a2.ticks) == (1024, 16, 10)
-    txt = b.WORKLOAD_TEXT[3].format(B=4096, dt=1e-3, N=32)
-    assert "4096" in txt and "walking" in txt and "N=32" in txt
+    assert (a2.instances, a2.horizon, a2.ticks, a2.mpc_dt, a2.push) == (1024, 16, 2000, 2e-2, 0.5)
+    a5 = b.parse(["--config", "5", "--gpus", "8"])
+    assert (a5.instances, a5.horizon, a5.ticks, a5.mpc_dt, a5.reset_every) == (4096, 48, 2000, 1e-2, 1)
+    c = b.parse(["--coupled"])
+    assert (c.ticks, c.mpc_dt, c.step_time) == (40, 1e-3, 0.2) and c.reset_every * c.ticks <= 480
+    c2 = b.parse(["--coupled", "--config", "2"])
+    assert (c2.ticks, c2.horizon, c2.push) == (10, 16, 1.0) and c2.reset_every * c2.ticks <= 230
+    txt = b.WORKLOAD_TEXT[3].format(B=4096, dt=1e-3, N=32, md=1e-2, push=1.0, st=0.5)
+    assert "4096" in txt and "walking" in txt and "N=32" in txt and "mpc_dt=0.01" in txt
+    assert b.HARD_FLAGS == 15
 
 
 def test_bench_gpus_flag_launches_ranks_and_propagates_failure():

@@ -254,3 +254,53 @@ def test_plant_of_the_oracle_is_physical():
     assert np.isfinite(r["state"]).all() and abs(w[5] + w[11] - o.mass * 9.81) < 0.03 * o.mass * 9.81
     assert (vf[:, 2] >= 0).all() and (np.hypot(vf[:, 0], vf[:, 1]) <= 0.7 * vf[:, 2] + 1e-12).all()
     assert abs(r["state"][2] - q0[2]) < 5e-3                       # it stands (sinks by the spring deflection only)
+
+
+def test_mpc_sample_time_independent_of_the_control_step():
+    """The reference's caller picks Clock(timeStep) (apps/offline/main.cpp:18) independently of ZMP(..., timeStep, ...) (:21) and
+    Mpc3dLip(dt, ...) (:39); k = int(t / dt_) uses the MPC's dt (mpcLinearPendulum.cpp:92).  Oracle(dt = mpc_dt).rollout(dt = control):
+    k follows int(t / mpc_dt) on the float-accumulated clock, the gain row / A, B come from mpc_dt, and the batch driver's mpc_dt
+    argument reproduces the single rollouts bit for bit."""
+    from oracle import pyoracle
+    from linearmpchumanoid_amd import trajectories
+    dt, mpc_dt, N, nt, B = 1e-3, 1e-2, 32, 45, 3
+    th = N * mpc_dt + 1e-9
+    o = Oracle(sim_time=1.0, dt=mpc_dt, horizon_time=th, do_ik=True)
+    assert o.horizon == N and o.n_zmp == int((1.0 + 0.5) / mpc_dt)
+    q0 = o.robot()["q"].copy()
+    plan = trajectories.walk_plan(1.0, mpc_dt, num_steps=2, time_per_step=0.3, ds_time=0.1, settle_time=0.02)
+    o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+    o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=0.03)
+    st0 = np.concatenate([q0, np.zeros(30)])
+    r = o.rollout(st0, 0.0, nt, dt=dt, log=True)
+    t, ks = 0.0, []
+    for _ in range(nt):
+        ks.append(int((t + dt) / mpc_dt))                          # the k4 stage of a tick is evaluated at t + dt (rk4.hpp:15)
+        t += dt                                                    # Clock::step
+    assert list(r["k"]) == ks and ks[-1] == 4 and ks[0] == 0
+    # Px / Pu of the preview use the MPC's dt, not the control step
+    Px, Pu = o.mpc_mats()
+    assert abs(Px[1, 1] - mpc_dt) < 1e-18 and abs(Pu[1, 0] - mpc_dt * mpc_dt / 2) < 1e-18
+    xs = np.array([0.03, 0.02, 0.05])
+    sec, st2, out = pyoracle.batch_rollout_ex(np.tile(st0, (B, 1)), 0.0, dt, nt, th, plan["zmp_x"], plan["zmp_y"], plan["phase"], plan["segs"],
+                                              plan["seg_of_sample"], xs, o.zcom, None, nthreads=2, mpc_dt=mpc_dt)
+    assert np.array_equal(st2[0], r["state"]) and np.array_equal(out[0], r["log"][-1])
+    assert not np.array_equal(st2[1], st2[0])
+    # mpc_dt = None keeps one value for both, as apps/offline/main.cpp passes
+    o1 = Oracle(sim_time=1.0, dt=dt, horizon_time=0.032, do_ik=True)
+    r1 = o1.rollout(st0, 0.0, 10)
+    _, s1, _ = pyoracle.batch_rollout_ex(st0[None, :], 0.0, dt, 10, 0.032, *o1.zmp(), zcom=o1.zcom)
+    assert np.array_equal(s1[0], r1["state"])
+
+
+def test_short_previews_diverge_and_a_third_of_a_second_does_not():
+    """Why the 1 kHz configurations need mpc_dt: with the MPC sample time tied to a 1 ms control step, N = 16..48 samples preview
+    16..48 ms, far below the LIPM's time constant sqrt(z/g) = 0.16 s, and the closed loop (which integrates the controller's own
+    acceleration, apps/offline/main.cpp:118-121) is a LIPM divergence; a 0.32 s preview (N = 32 x 10 ms or N = 16 x 20 ms) settles."""
+    def vmax(mpc_dt, N, nt):
+        o = Oracle(sim_time=nt * 1e-3 + 1.5, dt=mpc_dt, horizon_time=N * mpc_dt + 1e-9, do_ik=True)
+        v = np.zeros(30); v[0] = 0.1
+        r = o.rollout(np.concatenate([o.robot()["q"], v]), 0.0, nt, dt=1e-3)
+        return np.abs(r["state"][30:]).max()
+    assert vmax(1e-3, 32, 700) > 0.5                               # leaving (0.1 -> 0.97 rad/s and growing; NaN not long after)
+    assert vmax(1e-2, 32, 700) < 0.15 and vmax(2e-2, 16, 700) < 0.15
