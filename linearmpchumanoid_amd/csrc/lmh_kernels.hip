@@ -135,19 +135,15 @@ enum {
                       // [0..1] sum K_i zmp_x/y[k+i] | [2..3] sum K_i Px0_i, sum K_i Px1_i (per launch) | [4..21] foot polynomial
                       // position / velocity / acceleration, 3 per (foot, axis)
     P_END = 2602,
-    // ---- scratch, phase A1 (kinematics + Newton-Euler)
+    // ---- scratch, tree phases (kinematics, Newton-Euler, CRBA, Jacobian)
     S0 = P_END,
     A_LC = S0 + 0,    // 28 x 12 local transforms (dead after FK)
-    A_VEL = S0 + 0, A_ACCG = S0 + 168, A_ACC0 = S0 + 336, A_FG = S0 + 504, A_F0 = S0 + 672,
-    A_T = S0 + 840,   // 30 x 12
-    A_XE = S0 + 1200, A_XP = S0 + 1452, A_XB = S0 + 1536,
-    // ---- phase A2 (CRBA + Jacobian)
-    A_IC = S0 + 0,    // 28 x 36
-    A_YT = S0 + 1008, // 5 x 36
-    A_FB = S0 + 1788, // 2 x 24 x 6
-    A_XN = S0 + 2076, // 2 x 2 x 18
-    A_JL = S0 + 2148, // 2 x 6 x 12
-    A_XR = S0 + 2292, // 5 x 36 chain-root contributions to Ic_0 (CRBA; disjoint from the Jacobian's A_XN / A_JL)
+    A_VEL = S0 + 0, A_ACCG = S0 + 168, A_ACC0 = S0 + 336, A_FG = S0 + 504, A_F0 = S0 + 672,     // Newton-Euler: 28 x 6 each (wave 0)
+    A_JL = S0 + 0,    // 2 x 6 x 12 feet Jacobian in sole axes (wave 0, after its Newton-Euler pass)
+    A_T = S0 + 840,   // 30 x 12 world transforms (dead after phase_com_x; the IK kernel reads them later)
+    A_XF = S0 + 1200, // 28 x 36 : X_i = [A 0; B A] as full 6 x 6 images (row r contiguous, column r at stride 6)
+    A_XP = S0 + 2208, // 28 x 3 : p_i
+    A_XR = S0 + 2300, // 5 x 36 limb-root contributions to Ic_0 (CRBA, wave 1) | scratch of the helper wave's kinv_compute during the kinematics
     // ---- phase B (Woodbury + Schur)
     B_U = S0 + 0,     // 18 x 30
     B_K = S0 + 540,   // 25 x 19
@@ -245,29 +241,6 @@ struct LV {
     __device__ __forceinline__ LRef<R> operator[](int i) const { return LRef<R>{p + i}; }
 };
 
-// (X m)[k] for X = [E' 0; B E'],  m = [ang; lin]   (generalizedFunctions.cpp:11-19); branch-free
-template <typename R, typename MV>
-__device__ __forceinline__ R x_mot(const LV<R> E, const LV<R> Bm, const MV &m, int k)
-{
-    const bool up = k < 3;
-    const int a = up ? k : k - 3;
-    const LV<R> p = up ? E + a : Bm + 3 * a;
-    const int st = up ? 3 : 1;
-    const R t1 = p[0] * m[0] + p[st] * m[1] + p[2 * st] * m[2];
-    const R t2 = E[a] * m[3] + E[3 + a] * m[4] + E[6 + a] * m[5];
-    return up ? t1 : t1 + t2;
-}
-// (X' f)[k],  X' = [E B'; 0 E]; branch-free
-template <typename R>
-__device__ __forceinline__ R x_force(const LV<R> E, const LV<R> Bm, const LV<R> f, int k)
-{
-    const bool up = k < 3;
-    const int a = up ? k : k - 3;
-    const LV<R> g = up ? f : f + 3;
-    const R t1 = E[a * 3] * g[0] + E[a * 3 + 1] * g[1] + E[a * 3 + 2] * g[2];
-    const R t2 = Bm[a] * f[3] + Bm[3 + a] * f[4] + Bm[6 + a] * f[5];
-    return up ? t1 + t2 : t1;
-}
 // Lane exchange inside a 16-lane row through DPP (two 32-bit v_mov_dpp per double, ~10 cycles) instead of
 // ds_bpermute (an LDS round trip per step).  CTRL: 0xB1 = quad_perm[1,0,3,2] (lane ^ 1), 0x4E = quad_perm[2,3,0,1]
 // (lane ^ 2), 0x141 = row_half_mirror, 0x140 = row_mirror.  Needs a full exec mask (wave-uniform control flow).
@@ -769,8 +742,62 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
     WSYNC();
 }
 
+// ------------------------------------------------------------------ row-per-lane tree layout
+// The three tree recursions (Newton-Euler sweeps, composite inertias, feet Jacobian) keep their running quantity in REGISTERS:
+// DPP row rho = lane >> 4 is a limb (0 right leg: frames 1..7, 1 left leg: 8..14, 2 right arm 15..19 followed by the head 25, 26,
+// 3 left arm 20..24) and lane l16 = lane & 15 < 6 holds component r of the limb's current spatial vector / row r of its current 6 x 6.
+// "Multiply by X" is then six v_fmac_f64_dpp with row_newbcast (lane k of the own row supplies component k) -- no LDS round trip per
+// level, no index arithmetic: the coefficients come from the full 6 x 6 images A_XF of X_i = [A 0; B A] (row r contiguous, column r at
+// stride 6, the zero block stored), addressed as (per-lane base) + (compile-time offset of the level).
+// acc += sum_k lane_k(src) * m_k, k = 0..5; needs a full exec mask (wave-uniform control flow).
+__device__ __forceinline__ void bdot6(double &acc, double src, double m0, double m1, double m2, double m3, double m4, double m5)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"                                         // the result may feed a compiler-placed DPP read (the hazard recognizer does not see into the block)
+                 : "+v"(acc) : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5));
+}
+__device__ __forceinline__ void bdot6(float &acc, float src, float m0, float m1, float m2, float m3, float m4, float m5)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(acc) : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5));
+}
+template <typename R>
+__device__ __forceinline__ void bdot6(R &acc, R src, const R (&m)[6]) { bdot6(acc, src, m[0], m[1], m[2], m[3], m[4], m[5]); }
+
+// limb rows: frame of (row, depth d) = fb + d with fb = base of the limb; the right-arm row switches to the head frames at depth 5
+struct TreeRows {
+    int rho, r, fbB, fbA, adj;
+    bool on6;
+};
+__device__ __forceinline__ TreeRows tree_rows()
+{
+    TreeRows t;
+    const int lane = LANE;
+    t.rho = lane >> 4;
+    t.on6 = (lane & 15) < 6;
+    t.r = t.on6 ? (lane & 15) : 0;                                 // idle lanes shadow component 0 (their stores are switched off)
+    t.fbB = (t.rho == 0) ? 1 : (t.rho == 1) ? 8 : (t.rho == 2) ? 15 : 20;   // depths 0..4
+    t.fbA = (t.rho == 2) ? 20 : t.fbB;                             // depths 5, 6: the head (25, 26) rides behind the right arm
+    t.adj = (t.rho == 0) ? 0 : (t.rho == 1) ? 1 : 2;               // act(frame) = frame - adj on every limb (Robot.cpp:172)
+    return t;
+}
+
 // Robot::computeCoM (Robot.cpp:225-238) + parentTransMatrix/allVelocityMatrices/velocityMatrix
-// (Robot.cpp:276-298, generalizedFunctions.cpp:11-27: R' used as inverse, kept).
+// (Robot.cpp:276-298, generalizedFunctions.cpp:11-27: R' used as inverse, kept).  X_i = [A 0; B A], A = E', is written as a full
+// 6 x 6 image (A_XF, zero block included).
 // NW = 2: wave 0 owns frames 0..13 and the persistent copies, wave 1 the CoM and frames 14..27 (B of a frame needs
 // only that frame's E, p, so the two halves never wait for each other; the caller joins them).
 template <int NW, typename R>
@@ -803,7 +830,8 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
         const int fr = (lane < 60) ? lane / 12 : 0, el = lane % 12;
         const bool isE = el < 9;
         const int a = isE ? el / 3 : el - 9, col = isE ? el % 3 : 3;
-        const int sbase = isE ? A_XE + el : A_XP + (el - 9), sstr = isE ? 9 : 3;
+        // E[a][col] = A[col][a]: top-left and bottom-right blocks of the image; p -> A_XP
+        const int s1 = isE ? A_XF + 6 * col + a : A_XP + (el - 9), s2 = A_XF + 6 * (3 + col) + 3 + a, sstr = isE ? 36 : 3;
         constexpr int ROUNDS = (NW == 1) ? 6 : 3;
 #pragma unroll
         for (int u = 0; u < ROUNDS; u++) {
@@ -812,22 +840,33 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
             const int i = f_lo + (on ? fo : 0);
             const LV<R> Ti = L + A_T + 12 * i + col, Tp = L + A_T + 12 * f_parent(i);
             const R t0 = Tp[a], t1 = Tp[4 + a], t2 = Tp[8 + a];
-            const R s1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
-            const R s2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
-            if (on) L[sbase + sstr * i] = isE ? s1 : s1 + s2;
+            const R v1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
+            const R v2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
+            const R val = isE ? v1 : v1 + v2;
+            if (on) { L[s1 + sstr * i] = val; if (isE) L[s2 + 36 * i] = val; }
         }
     }
     if (wid == 0 && lane < 12) {                                   // frame 0: E = R0, p = p0
         const LV<R> T0 = L + A_T;
-        if (lane < 9) L[A_XE + lane] = T0[(lane / 3) * 4 + lane % 3];
-        else L[A_XP + (lane - 9)] = T0[(lane - 9) * 4 + 3];
+        if (lane < 9) {
+            const int a = lane / 3, c = lane % 3;
+            const R v = T0[a * 4 + c];
+            L[A_XF + 6 * c + a] = v; L[A_XF + 6 * (3 + c) + 3 + a] = v;
+        } else L[A_XP + (lane - 9)] = T0[(lane - 9) * 4 + 3];
+    }
+    {   // the zero block of every image of this wave's frames (the QP phases reuse this scratch, so it is rewritten per evaluation)
+        const int z_lo = (NW == 2 && wid == 1) ? 14 : 0, z_n = (NW == 1) ? 28 : 14;
+        for (int e = lane; e < 9 * z_n; e += 64) {
+            const int f = z_lo + e / 9, rr = (e % 9) / 3, c = e % 3;
+            L[A_XF + 36 * f + 6 * rr + 3 + c] = 0.0;
+        }
     }
     WSYNC();
     SUBSTAMP(3);
     const int b_lo = (NW == 2 && wid == 1) ? 14 : 0, b_n = (NW == 1) ? 28 : 14;
-    {   // B = (-E') [p]x, entry (a, b) = sg1 E[i1] p[j1] + sg2 E[i2] p[j2]; lane = (frame slot < 7, entry < 9), seven frames per round
+    {   // B = (-E') [p]x, entry (a, b) = sg1 E[r1][a] p[j1] + sg2 E[r2][a] p[j2]; lane = (frame slot < 7, entry < 9), seven frames per round
         const int fr = (lane < 63) ? lane / 9 : 0, e9 = lane % 9, a = e9 / 3, bb = e9 % 3;
-        const int i1 = (bb == 0) ? 3 + a : a, j1 = (bb == 2) ? 1 : 2, i2 = (bb == 2) ? 3 + a : 6 + a, j2 = (bb == 0) ? 1 : 0;
+        const int r1 = (bb == 0) ? 1 : 0, j1 = (bb == 2) ? 1 : 2, r2 = (bb == 2) ? 1 : 2, j2 = (bb == 0) ? 1 : 0;
         const R sg1 = (bb == 1) ? (R)1 : (R)-1, sg2 = (bb == 1) ? (R)-1 : (R)1;
         constexpr int ROUNDS = (NW == 1) ? 4 : 2;
 #pragma unroll
@@ -835,25 +874,28 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
             const int fo = 7 * u + fr;
             const bool on = (lane < 63) && (fo < b_n);
             const int i = b_lo + (on ? fo : 0);
-            const LV<R> E = L + A_XE + 9 * i, p = L + A_XP + 3 * i;
-            const R val = (sg1 * (R)E[i1]) * (R)p[j1] + (sg2 * (R)E[i2]) * (R)p[j2];
-            if (on) L[A_XB + 9 * i + e9] = val;
+            const LV<R> X = L + A_XF + 36 * i + 6 * a, p = L + A_XP + 3 * i;      // E[row][a] = A[a][row]: contiguous in the row index
+            const R val = (sg1 * (R)X[r1]) * (R)p[j1] + (sg2 * (R)X[r2]) * (R)p[j2];
+            if (on) L[A_XF + 36 * i + 6 * (3 + a) + bb] = val;
         }
     }
     WSYNC();
     SUBSTAMP(4);
     if (wid == 0) {
-        // persistent copies: T0, T7, T14, X0
+        // persistent copies: T0, T7, T14, X0 = E0 (9) | p0 (3) | B0 (9)
         if (lane < 36) L[P_TB + lane] = L[A_T + 12 * ((lane < 12) ? 0 : (lane < 24) ? 7 : 14) + lane % 12];
-        if (lane < 21) L[P_X0 + lane] = (lane < 9) ? L[A_XE + lane] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XB + lane - 12];
+        if (lane < 21) {
+            const int e = (lane < 9) ? lane : (lane < 12) ? 0 : lane - 12, a = e / 3, b = e % 3;
+            L[P_X0 + lane] = (lane < 9) ? L[A_XF + 6 * b + a] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XF + 6 * (3 + a) + b];
+        }
         // base-frame reordered velocities, stale (Robot::v_) and fresh: swapBaseVelocityAndRefToWorldFrame
         if (lane < 60) {
             const int which = lane / 30, i = lane % 30;
             const LV<R> v = L + (which ? P_V : P_VP);
             R val;
             if (i < 6) {
-                const R m[6] = {v[3], v[4], v[5], v[0], v[1], v[2]};
-                val = x_mot<R>(L + A_XE, L + A_XB, m, i);
+                const LV<R> X = L + A_XF + 6 * i;                  // row i of X_0
+                val = ((R)X[0] * (R)v[3] + (R)X[1] * (R)v[4] + (R)X[2] * (R)v[5]) + ((R)X[3] * (R)v[0] + (R)X[4] * (R)v[1] + (R)X[5] * (R)v[2]);
             } else val = v[i];
             L[(which ? P_VHN : P_VHS) + i] = val;
         }
@@ -871,46 +913,34 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
 {
     const int lane = LANE;
     constexpr int VSRC = PLANT ? (int)P_VHN : (int)P_VHS;
+    constexpr int CDST = PLANT ? (int)P_VHS : (int)P_C;
+    const TreeRows tr = tree_rows();
+    const int r = tr.r;
     // base: vel0 = vhat[0:6]; accg0 = X0 * [0 0 0 0 0 9.81]; acc00 = 0
-    if (lane < 6) {
-        L[A_VEL + lane] = L[VSRC + lane];
-        const R g[6] = {0, 0, 0, 0, 0, 9.81};
-        L[A_ACCG + lane] = x_mot<R>(L + A_XE, L + A_XB, g, lane);
-        L[A_ACC0 + lane] = 0.0;
-    }
-    {   // velocity and acceleration sweeps, software-pipelined by one level: step d computes vel at chain depth d
-        // and acc (with / without gravity) at depth d-1.  Lanes (chain, which, k); straight-line code with guarded
-        // stores (operand addresses are always inside the LDS arrays) so that each step is one basic block.
-        const int c = (lane < 60) ? lane / 12 : 4, which = (lane % 12) / 6, k = lane % 6;
-        const int base = f_chain_base(c);
-        const int nact = (c < 2) ? 6 : (c < 4) ? 5 : 2;           // actuated frames on the chain
-        const int nacc = (c < 2) ? 7 : nact;                      // legs: the sole frame needs its acceleration too
-        const int adj = (c == 0) ? 0 : (c == 1) ? 1 : 2;          // act(frame) = frame - adj on this chain (Robot.cpp:172)
-        const int abase = which ? A_ACC0 : A_ACCG;
-        const bool live = lane < 60;
-        const int cs_ix = (k == 0) ? 1 : (k == 1) ? 0 : (k == 3) ? 4 : (k == 4) ? 3 : 0;       // crm(v) S component of this lane
-        const R cs_sg = (k == 0 || k == 3) ? (R)1 : (k == 1 || k == 4) ? (R)-1 : (R)0;
+    const R bv = L[VSRC + r], bg = (R)L[A_XF + 6 * r + 5] * (R)9.81;
+    if (lane < 6) { L[A_VEL + lane] = bv; L[A_ACCG + lane] = bg; L[A_ACC0 + lane] = 0.0; }
+    {   // velocity and acceleration sweeps down the limbs, one frame per depth, recurrences in registers:
+        // v_i = X_i v_p + S qd_i; a_i = X_i a_p + crm(v_i) S qd_i (with / without gravity in the base acceleration)
+        const R s2 = (r == 2) ? (R)1 : (R)0;                       // S = e_z (angular): component 2
+        const R ca = (r == 0 || r == 3) ? (R)1 : (R)0, cb = (r == 1 || r == 4) ? (R)-1 : (R)0;   // crm(v) S = (wy, -wx, 0, vy, -vx, 0)
+        R pv = bv, pg = bg, p0 = 0;
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
-            WSYNC();
-            // ---- velocity, depth index d
-            const int iv = base + ((d < nact) ? d : 0);
-            const int pv = (d == 0) ? 0 : iv - 1;
-            R vval = x_mot<R>(L + A_XE + 9 * iv, L + A_XB + 9 * iv, L + A_VEL + 6 * pv, k);
-            const R qdv = L[VSRC + 5 + iv - adj];
-            vval += (k == 2) ? qdv : 0.0;
-            // ---- acceleration, depth index d-1
-            const int e = d - 1;
-            const int ia = base + ((e >= 0 && e < nacc) ? e : 0);
-            const int pa = (e <= 0) ? 0 : ia - 1;
-            R aval = x_mot<R>(L + A_XE + 9 * ia, L + A_XB + 9 * ia, L + abase + 6 * pa, k);
-            const LV<R> vi = L + A_VEL + 6 * ia;
-            const R qda = L[VSRC + 5 + ia - adj];
-            // crm(v) S = (w x ez ; v x ez) = (wy, -wx, 0, vy, -vx, 0)
-            const R cs = cs_sg * (R)vi[cs_ix];                     // one load: (index, sign) derived once per pass
-            aval += (e < nact) ? cs * qda : 0.0;
-            if (live && which == 0 && d < nact) L[A_VEL + 6 * iv + k] = vval;
-            if (live && e >= 0 && e < nacc) L[abase + 6 * ia + k] = aval;
+        for (int d = 0; d < 7; d++) {
+            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
+            const LV<R> X = L + A_XF + 36 * f + 6 * r;
+            const R x[6] = {X[0], X[1], X[2], X[3], X[4], X[5]};
+            R qd = L[VSRC + 5 + f - tr.adj];
+            if (d == 6) qd = (tr.rho < 2) ? (R)0 : qd;             // the soles carry no joint
+            if (d == 5) { pv = (tr.rho == 2) ? bv : pv; pg = (tr.rho == 2) ? bg : pg; p0 = (tr.rho == 2) ? (R)0 : p0; }   // the head starts from the base
+            R v = s2 * qd;
+            bdot6(v, pv, x);
+            const R cs = (ca * dpp_row<0x101>(v) + cb * dpp_row<0x111>(v)) * qd;      // row_shl:1 (lane + 1) | row_shr:1 (lane - 1)
+            R ag = cs, a0 = cs;
+            bdot6(ag, pg, x);
+            bdot6(a0, p0, x);
+            const bool on = tr.on6 && (d < 5 || tr.rho != 3);      // the left-arm row idles behind its five frames
+            if (on) { L[A_VEL + 6 * f + r] = v; L[A_ACCG + 6 * f + r] = ag; L[A_ACC0 + 6 * f + r] = a0; }
+            pv = v; pg = ag; p0 = a0;
         }
     }
     WSYNC();
@@ -946,94 +976,76 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
         LV<R> fo = L + (which ? A_F0 : A_FG) + 6 * i;
         if (fon) { fo[0] = n0; fo[1] = n1; fo[2] = n2; fo[3] = f0; fo[4] = f1; fo[5] = f2; }
     }
+    WSYNC();
     SUBSTAMP(7);
-    {   // backward sweep, lanes (chain, which, k): depth 6 -> 2 accumulate into the parent (straight-line, guarded stores)
-        const int c = (lane < 60) ? lane / 12 : 4, which = (lane % 12) / 6, k = lane % 6;
-        const int fb = which ? A_F0 : A_FG;
-        const int cb0 = f_chain_base(c);
-        const int nact = (c < 2) ? 6 : (c < 4) ? 5 : 2;
+    {   // backward sweep up the limbs: fs_i = f_i + X_c' fs_c (child c), C[joint of i] = fs_i[2]; the limb roots (and the head's) are parked
+        // for the base sum.  Depth 6 is the massless sole on the leg rows (skipped) and the head's leaf on the right-arm row.
+        R cg = 0, c0 = 0;
 #pragma unroll
-        for (int d = 5; d >= 1; d--) {
-            WSYNC();
-            const bool on = (lane < 60) && (d < nact);
-            const int i = cb0 + (on ? d : 1);                      // parent of a depth >= 2 frame is i - 1
-            const R add = x_force(L + A_XE + 9 * i, L + A_XB + 9 * i, L + fb + 6 * i, k);
-            const R old = L[fb + 6 * (i - 1) + k];
-            if (on) L[fb + 6 * (i - 1) + k] = old + add;
+        for (int d = 6; d >= 0; d--) {
+            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
+            const bool active = (d < 5) || (d == 5 && tr.rho != 3) || (d == 6 && tr.rho == 2);
+            const bool root = (d == 0) || (d == 5 && tr.rho == 2);
+            const R fg = (R)L[A_FG + 6 * f + r] + cg, f0 = (R)L[A_F0 + 6 * f + r] + c0;
+            if (tr.on6 && active && (lane & 15) == 2) L[CDST + 5 + f - tr.adj] = fg;    // C[5 + act(frame)] (with gravity)
+            const LV<R> X = L + A_XF + 36 * f + r;                 // column r of X_f
+            const R w[6] = {X[0], X[6], X[12], X[18], X[24], X[30]};
+            R ng = 0, n0 = 0;
+            bdot6(ng, fg, w);
+            bdot6(n0, f0, w);
+            if (tr.on6 && active && root) {                        // A_VEL is dead after the body forces: slot = chain (RL, LL, RA, LA, head)
+                const int ch = (d == 5) ? 4 : tr.rho;
+                L[A_VEL + 12 * ch + r] = ng; L[A_VEL + 12 * ch + 6 + r] = n0;
+            }
+            const bool keep = active && !root;
+            cg = keep ? ng : (R)0; c0 = keep ? n0 : (R)0;
         }
-        WSYNC();
-        SUBSTAMP(8);
-        {   // the five chain roots project onto the base in parallel, then are summed in the reference's order
-            const R contrib = x_force(L + A_XE + 9 * cb0, L + A_XB + 9 * cb0, L + fb + 6 * cb0, k);
-            if (lane < 60) L[A_VEL + 12 * c + 6 * which + k] = contrib;       // A_VEL is dead after the body forces
-        }
-        WSYNC();
-        if (lane < 12) {                                           // base: head, LA, RA, LL, RL (Dynamics.cpp:157-162 order)
-            const int w2 = lane / 6, k2 = lane % 6;
-            R acc = L[(w2 ? A_F0 : A_FG) + k2];
+    }
+    WSYNC();
+    SUBSTAMP(8);
+    if (lane < 12) {                                               // base: head, LA, RA, LL, RL (Dynamics.cpp:157-162 order)
+        const int w2 = lane / 6, k2 = lane % 6;
+        R acc = L[(w2 ? A_F0 : A_FG) + k2];
 #pragma unroll
-            for (int cc = 4; cc >= 0; cc--) acc += L[A_VEL + 12 * cc + 6 * w2 + k2];
-            if constexpr (PLANT) { if (w2 == 0) L[P_VHS + k2] = acc; }
-            else { if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc; }
-        }
-        if (lane >= 16 && lane < 40) L[(PLANT ? (int)P_VHS : (int)P_C) + 6 + (lane - 16)] = L[A_FG + 6 * f_jframe(lane - 16) + 2];
-        if (!PLANT && lane >= 40 && lane < 52) {                   // Jpqp = blkdiag(R,R) acc0[sole]
-            const int foot = (lane - 40) / 6, k2 = (lane - 40) % 6, r = k2 % 3, o = (k2 / 3) * 3;
-            const LV<R> T = L + P_TB + 12 * (1 + foot), a = L + A_ACC0 + 6 * (foot ? 14 : 7);
-            L[P_JPQP + 6 * foot + k2] = T[4 * r] * a[o] + T[4 * r + 1] * a[o + 1] + T[4 * r + 2] * a[o + 2];
-        }
+        for (int cc = 4; cc >= 0; cc--) acc += L[A_VEL + 12 * cc + 6 * w2 + k2];
+        if constexpr (PLANT) { if (w2 == 0) L[P_VHS + k2] = acc; }
+        else { if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc; }
+    }
+    if (!PLANT && lane >= 40 && lane < 52) {                       // Jpqp = blkdiag(R,R) acc0[sole]
+        const int foot = (lane - 40) / 6, k2 = (lane - 40) % 6, rr = k2 % 3, o = (k2 / 3) * 3;
+        const LV<R> T = L + P_TB + 12 * (1 + foot), a = L + A_ACC0 + 6 * (foot ? 14 : 7);
+        L[P_JPQP + 6 * foot + k2] = T[4 * rr] * a[o] + T[4 * rr + 1] * a[o + 1] + T[4 * rr + 2] * a[o + 2];
     }
     WSYNC();
 }
 
-// Dynamics::computeM (CRBA, Dynamics.cpp:62-101) -> Mtop = [Ic0 | F2], Hl (per-limb joint blocks)
-// Lane map for the composite-inertia recursion: 12 lanes per chain = (row r, 3-column block cb); the
-// running composite inertia of a chain lives in the registers of its 12 lanes (three entries each), so the
-// recursion never round-trips it through LDS; all five chains advance one level per pass.
-
-// rows of the 6x6 body inertia [Ibar, [h]x; -[h]x, m 1] (Dynamics.cpp:4-13): entries (r, 3cb..3cb+2)
-// Which three entries of the 6x6 body inertia a lane owns depends on its (row r, column block cb) only, so the
-// selection is derived ONCE per pass as (record index, sign) pairs: out[k] = sg[k] * mo[idx[k]] -- three loads and
-// three multiplies per use instead of a dozen selects.
+// Dynamics::computeM (CRBA, Dynamics.cpp:62-101) -> Mtop = [Ic0 | F2], Hl (per-limb joint blocks).
+// Row-per-lane: lane r of a limb's row holds row r of the composite inertia Ic of the limb's current frame; one iteration folds a frame
+// into its parent: Y = Ic X (27 FMAs on the 18 entries of X, read at row-uniform addresses), Z = X' Y (36 v_fmac_f64_dpp: lane k supplies
+// row k of Y), Ic_parent = I_parent + Z.  The joint columns f = Ic S ride along: every column still on its way to the base is carried
+// one frame up per iteration (six DPP FMAs), leaving H(parent joint, column's joint) = f[2] on the way and F2 at the limb root.
+// Seven iterations: the right-arm row folds the head's two frames first (it 0, 1), the legs start at it 1, the arms at it 2.
+//
+// row r of the 6x6 body inertia [Ibar, [h]x; -[h]x, m 1] (Dynamics.cpp:4-13) from the 13-entry model record: out[c] = sg[c] * mo[idx[c]]
 template <typename R>
-struct BodyRowSel { int i0, i1, i2; R s0, s1, s2; };
+struct BodyRow6 { int i[6]; R s[6]; };
 template <typename R>
-__device__ __forceinline__ BodyRowSel<R> body_row_sel(int r, int cb)
+__device__ __forceinline__ BodyRow6<R> body_row6(int r)
 {
     const bool up = r < 3;
     const int a = up ? r : r - 3;
-    const bool diag = (up == (cb == 0));                           // (up, cb=0): Ibar row; (down, cb=1): m e_a
-    BodyRowSel<R> q;
-    if (diag && up) { q.i0 = 3 * a; q.i1 = 3 * a + 1; q.i2 = 3 * a + 2; q.s0 = 1; q.s1 = 1; q.s2 = 1; }
-    else if (diag) { q.i0 = 12; q.i1 = 12; q.i2 = 12; q.s0 = (a == 0) ? 1 : 0; q.s1 = (a == 1) ? 1 : 0; q.s2 = (a == 2) ? 1 : 0; }
-    else {
-        // row a of [h]x = [0 -hz hy; hz 0 -hx; -hy hx 0] with h = mo[9..11]; the lower-left block is its negative
-        const R sg = up ? (R)1 : (R)-1;
-        q.i0 = (a == 1) ? 11 : 10; q.s0 = (a == 0) ? (R)0 : (a == 1) ? sg : -sg;
-        q.i1 = (a == 0) ? 11 : 9;  q.s1 = (a == 1) ? (R)0 : (a == 0) ? -sg : sg;
-        q.i2 = (a == 0) ? 10 : 9;  q.s2 = (a == 2) ? (R)0 : (a == 0) ? sg : -sg;
+    BodyRow6<R> q;
+    // [h]x row a = [0 -hz hy; hz 0 -hx; -hy hx 0] with h = mo[9..11]
+    const int hi0 = (a == 1) ? 11 : 10, hi1 = (a == 0) ? 11 : 9, hi2 = (a == 0) ? 10 : 9;
+    const R hs0 = (a == 0) ? (R)0 : (a == 1) ? (R)1 : (R)-1, hs1 = (a == 1) ? (R)0 : (a == 0) ? (R)-1 : (R)1, hs2 = (a == 2) ? (R)0 : (a == 0) ? (R)1 : (R)-1;
+    if (up) {                                                       // [Ibar row a | [h]x row a]
+        q.i[0] = 3 * a; q.i[1] = 3 * a + 1; q.i[2] = 3 * a + 2; q.s[0] = 1; q.s[1] = 1; q.s[2] = 1;
+        q.i[3] = hi0; q.i[4] = hi1; q.i[5] = hi2; q.s[3] = hs0; q.s[4] = hs1; q.s[5] = hs2;
+    } else {                                                        // [-[h]x row a | m e_a]
+        q.i[0] = hi0; q.i[1] = hi1; q.i[2] = hi2; q.s[0] = -hs0; q.s[1] = -hs1; q.s[2] = -hs2;
+        q.i[3] = 12; q.i[4] = 12; q.i[5] = 12; q.s[3] = (a == 0) ? 1 : 0; q.s[4] = (a == 1) ? 1 : 0; q.s[5] = (a == 2) ? 1 : 0;
     }
     return q;
-}
-template <typename R>
-__device__ __forceinline__ void body_row3(const LV<R> mo, const BodyRowSel<R> &q, R out[3])
-{
-    out[0] = q.s0 * (R)mo[q.i0]; out[1] = q.s1 * (R)mo[q.i1]; out[2] = q.s2 * (R)mo[q.i2];
-}
-template <typename R>
-__device__ __forceinline__ void crba_z(const LV<R> L, int i, int slot, int r, int cb, R out[3])   // (X_i' Y)(r, 3cb..)
-{
-    const LV<R> E = L + A_XE + 9 * i, Bm = L + A_XB + 9 * i, Y = L + A_YT + 36 * slot + 3 * cb;
-    const bool up = r < 3;
-    const int a = up ? r : r - 3;
-    const R mu = up ? (R)1 : (R)0;                                // the upper rows also see E' on the first three rows of Y
-    const R lo0 = mu * (R)E[3 * a], lo1 = mu * (R)E[3 * a + 1], lo2 = mu * (R)E[3 * a + 2];
-    const LV<R> H = up ? Bm + a : E + 3 * a;                       // column a of B (stride 3) | row a of E: picked by address
-    const int hst = up ? 3 : 1;
-    const R hi0 = H[0], hi1 = H[hst], hi2 = H[2 * hst];
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-        out[c] = lo0 * Y[c] + lo1 * Y[6 + c] + lo2 * Y[12 + c] + hi0 * Y[18 + c] + hi1 * Y[24 + c] + hi2 * Y[30 + c];
 }
 
 template <typename R>
@@ -1041,136 +1053,140 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
 {
     const int lane = LANE;
     SUBSTAMP(9);
-    const int ch = lane / 12, t = lane % 12, r = t >> 1, cb = t & 1;
-    const int nact = (ch < 2) ? 6 : (ch < 4) ? 5 : 2;             // actuated frames of this lane's chain
-    const int cbase = f_chain_base(ch < 5 ? ch : 4);
-    const BodyRowSel<R> bsel = body_row_sel<R>(r, cb);
-    R ic[3] = {0.0, 0.0, 0.0};                               // Ic_i[r][3cb .. 3cb+2] of the frame being folded
+    const TreeRows tr = tree_rows();
+    const int r = tr.r;
+    const BodyRow6<R> bs = body_row6<R>(r);
+    for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;        // entries outside a limb's block stay zero
+    // limb-local joint index of the frame at depth d: d (legs, arms), d - 5 (head); first joint of the limb
+    const int jst = (tr.rho == 0) ? 0 : (tr.rho == 1) ? 6 : (tr.rho == 2) ? 12 : 17;
+    R Z[6] = {0, 0, 0, 0, 0, 0};                                   // X' Ic X of the frame folded last (0 in front of a leaf)
+    R Fc[7];                                                       // joint columns on their way up, slot = iteration that created them
 #pragma unroll
-    for (int dl = 6; dl >= 1; dl--) {                              // chain depth of the frames folded into their parents
-        const bool on = (lane < 60) && (dl <= nact);
-        const int i = cbase + (on ? dl - 1 : 0);                   // safe frame index for the idle lanes
-        R leaf[3];
-        body_row3(L + P_MODEL + LMH_BODY_STRIDE * i, bsel, leaf);
-        if (dl == nact) { ic[0] = leaf[0]; ic[1] = leaf[1]; ic[2] = leaf[2]; }   // leaf: Ic = I (Dynamics.cpp:72)
-        if (on && cb == 0) L[A_FB + 6 * (f_act(i) - 1) + r] = ic[2];             // f = Ic_i S for the joint columns
-        const R p0 = dpp_row<0xB1>(ic[0]), p1 = dpp_row<0xB1>(ic[1]), p2 = dpp_row<0xB1>(ic[2]);   // partner lane ^ 1 (cb ^ 1)
-        const R lo[3] = {cb ? p0 : ic[0], cb ? p1 : ic[1], cb ? p2 : ic[2]};
-        const R hi[3] = {cb ? ic[0] : p0, cb ? ic[1] : p1, cb ? ic[2] : p2};
-        WSYNC();                                                   // A_YT of the previous level has been consumed
+    for (int it = 0; it < 7; it++) {
+        const int d = 6 - it;
+        const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;             // legs: frames 6..1 / 13..8 at it 1..6; right-arm row: 26, 25, 19..15; left arm: 24..20 at it 2..6
+        const bool active = (it >= 2) || (it == 1 && tr.rho != 3) || (it == 0 && tr.rho == 2);
+        const bool root = (it == 6) || (it == 1 && tr.rho == 2);
+        const bool head = (it < 2) && (tr.rho == 2);               // the right-arm row folds the head first
+        const int jbase = head ? 22 : jst, dl = head ? d - 5 : d;  // this frame's joint = jbase + dl
+        // ---- Ic = I_f + Z
+        const LV<R> mo = L + P_MODEL + LMH_BODY_STRIDE * f;
+        R Ic[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) Ic[c] = fma(bs.s[c], (R)mo[bs.i[c]], Z[c]);
+        Fc[it] = Ic[2];                                            // f = Ic S
+        if (tr.on6 && active && (lane & 15) == 2) L[P_HL + 6 * (jbase + dl) + dl] = Ic[2];       // H(a, a) = f[2]
+        // ---- Y = Ic X,  X = [A 0; B A]
+        const LV<R> X = L + A_XF + 36 * f;
+        R Y[6];
         {
-            const LV<R> E = L + A_XE + 9 * i;
-            const R l0 = cb ? 0.0 : lo[0], l1 = cb ? 0.0 : lo[1], l2 = cb ? 0.0 : lo[2];
-            // second operand: row c of E (cb = 1) or column c of B (cb = 0) -- selected by ADDRESS (base, stride), three loads
-            const LV<R> Xs = L + (cb ? A_XE : A_XB) + 9 * i;
-            const int xst = cb ? 1 : 3, xcs = cb ? 3 : 1;
-            R y[3];
+            R A_[9], B_[9];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { A_[3 * k + c] = X[6 * k + c]; B_[3 * k + c] = X[6 * (3 + k) + c]; }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const R x0 = Xs[xcs * c], x1 = Xs[xcs * c + xst], x2 = Xs[xcs * c + 2 * xst];
-                y[c] = l0 * E[3 * c] + l1 * E[3 * c + 1] + l2 * E[3 * c + 2] + hi[0] * x0 + hi[1] * x1 + hi[2] * x2;
-            }
-            if (on) { LV<R> yo = L + A_YT + 36 * ch + 6 * r + 3 * cb; yo[0] = y[0]; yo[1] = y[1]; yo[2] = y[2]; }
-        }
-        WSYNC();
-        {
-            R z[3], bp3[3];
-            crba_z(L, i, (lane < 60) ? ch : 0, r, cb, z);
-            body_row3(L + P_MODEL + LMH_BODY_STRIDE * ((i > 0) ? i - 1 : 0), bsel, bp3);
-            if (dl >= 2) {                                         // Ic[parent] = Ic[parent] + X' Ic X (Dynamics.cpp:82), parent = i-1
-                if (on) { ic[0] = bp3[0] + z[0]; ic[1] = bp3[1] + z[1]; ic[2] = bp3[2] + z[2]; }
-            } else if (on) {                                       // depth 1: park the contribution to the base
-                const int slot = (ch == 4) ? 0 : 4 - ch;           // reference order head, LA, RA, LL, RL
-                LV<R> o = L + A_XR + 36 * slot + 6 * r + 3 * cb;
-                o[0] = z[0]; o[1] = z[1]; o[2] = z[2];
+                Y[c] = Ic[0] * A_[c] + Ic[1] * A_[3 + c] + Ic[2] * A_[6 + c] + Ic[3] * B_[c] + Ic[4] * B_[3 + c] + Ic[5] * B_[6 + c];
+                Y[3 + c] = Ic[3] * A_[c] + Ic[4] * A_[3 + c] + Ic[5] * A_[6 + c];
             }
         }
+        // ---- Z = X' Y and the joint columns one frame up: lane r applies column r of X
+        const LV<R> Xc = L + A_XF + 36 * f + r;
+        const R w[6] = {Xc[0], Xc[6], Xc[12], Xc[18], Xc[24], Xc[30]};
+        R Zn[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 6; c++) bdot6(Zn[c], Y[c], w);
+        // columns alive: the head's (slots 0, 1) until the head's root at it 1, the limb's own from its leaf on
+#pragma unroll
+        for (int ci = (it >= 2 ? 1 : 0); ci <= it; ci++) {
+            R t = 0;
+            bdot6(t, Fc[ci], w);
+            Fc[ci] = t;
+            // the column's joint: created at iteration ci on this row
+            const bool chead = ci < 2 && tr.rho == 2 && it < 2;
+            const int cd = 6 - ci, cj_l = chead ? cd - 5 : cd, cj = (chead ? 22 : jst) + cj_l;
+            const bool exists = (tr.rho == 2) ? (it < 2 ? true : ci >= 2) : (tr.rho == 3 ? ci >= 2 : ci >= 1);
+            if (tr.on6 && active && exists) {
+                if (root) L[P_MTOP + 30 * r + 6 + cj] = t;         // F2 column
+                else if ((lane & 15) == 2) {                       // H(parent joint, column joint) = f[2], both triangles
+                    const int pj_l = dl - 1, pj = jbase + pj_l;
+                    L[P_HL + 6 * pj + cj_l] = t; L[P_HL + 6 * cj + pj_l] = t;
+                }
+            }
+        }
+        if (tr.on6 && active && root) {                            // park X' Ic X of the limb root for the base sum (reference order head, LA, RA, LL, RL)
+            const int slot = (it == 1) ? 0 : 4 - tr.rho;
+            LV<R> o = L + A_XR + 36 * slot + 6 * r;
+#pragma unroll
+            for (int c = 0; c < 6; c++) o[c] = Zn[c];
+        }
+        const bool keep = active && !root;
+#pragma unroll
+        for (int c = 0; c < 6; c++) Z[c] = (it < 2) ? (keep ? Zn[c] : (R)0) : Zn[c];
     }
     WSYNC();
     SUBSTAMP(10);
-    if (lane < 12) {                                               // Ic0 = I0 + head + LA + RA + LL + RL (Dynamics.cpp:80-82 order)
-        R acc[3];
-        body_row3(L + P_MODEL, bsel, acc);
+    if (lane < 6) {                                                // Ic0 = I0 + head + LA + RA + LL + RL (Dynamics.cpp:80-82 order)
+        const LV<R> mo = L + P_MODEL;
+        R acc[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[c] = bs.s[c] * (R)mo[bs.i[c]];
 #pragma unroll
         for (int sl = 0; sl < 5; sl++) {
-            const LV<R> o = L + A_XR + 36 * sl + 6 * r + 3 * cb;
-            acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2];
+            const LV<R> o = L + A_XR + 36 * sl + 6 * r;
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[c] += o[c];
         }
-        LV<R> mt = L + P_MTOP + 30 * r + 3 * cb;
-        mt[0] = acc[0]; mt[1] = acc[1]; mt[2] = acc[2];
+        LV<R> mt = L + P_MTOP + 30 * r;
+#pragma unroll
+        for (int c = 0; c < 6; c++) mt[c] = acc[c];
     }
-    WSYNC();
     SUBSTAMP(11);
-    // joint columns: f = Ic_i S, walked up the chain (Dynamics.cpp:83-93); 2 lanes per joint (k<3 | k>=3)
-    for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;
-    const int ja = (lane < 48) ? lane >> 1 : 0, hf = lane & 1;
-    const int jf = f_jframe(ja), jst = f_jstart(ja), jd = ja - jst + 1;
-    if (lane < 48 && hf == 0) L[P_HL + 6 * ja + (ja - jst)] = L[A_FB + 6 * ja + 2];
-#pragma unroll
-    for (int sdep = 1; sdep <= 6; sdep++) {                         // straight-line steps, guarded stores
-        WSYNC();
-        const int cur = (sdep - 1) & 1;
-        const bool on = (lane < 48) && (sdep <= jd);
-        const int j = on ? jf - (sdep - 1) : jf;                    // frame whose X' is applied
-        const LV<R> E = L + A_XE + 9 * j, Bm = L + A_XB + 9 * j, f = L + A_FB + 144 * cur + 6 * ja;
-        const LV<R> g = hf ? f + 3 : f;
-        R o3[3];
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) {
-            const R t1 = E[3 * kk] * g[0] + E[3 * kk + 1] * g[1] + E[3 * kk + 2] * g[2];
-            const R t2 = Bm[kk] * f[3] + Bm[3 + kk] * f[4] + Bm[6 + kk] * f[5];
-            o3[kk] = hf ? t1 : t1 + t2;
-        }
-        if (on) {
-            LV<R> fo = L + A_FB + 144 * (cur ^ 1) + 6 * ja + 3 * hf;
-            fo[0] = o3[0]; fo[1] = o3[1]; fo[2] = o3[2];
-            if (sdep == jd) {
-                LV<R> mt = L + P_MTOP + 30 * (3 * hf) + 6 + ja;   // F2 column
-                mt[0] = o3[0]; mt[30] = o3[1]; mt[60] = o3[2];
-            } else if (hf == 0) {
-                const int aj = ja - sdep;                           // joint of parent(j)
-                L[P_HL + 6 * aj + (ja - jst)] = o3[2];
-                L[P_HL + 6 * ja + (aj - jst)] = o3[2];
-            }
-        }
-    }
     WSYNC();
 }
 
 // Kinematics::feetJacobian / frameJacobian (invKinematics.cpp:72-149), chain products in the
-// reference's association ((X7 X6) X5 ...); X kept as (A, B) with X = [A 0; B A].
+// reference's association ((X7 X6) X5 ...).  Lane r of a leg's row holds row r of the running product Xn: Xn <- Xn X_f is row-wise
+// (27 FMAs on the 18 entries of X_f, read at row-uniform addresses), no exchange between lanes at all; the z column Xn S of
+// every intermediate is the joint's Jacobian column.
 template <typename R>
 __device__ __forceinline__ void phase_jacobian(LV<R> L)
 {
     const int lane = LANE;
-    const int foot = lane / 18, el = lane % 18, half = el / 9, r = (el % 9) / 3, c = el % 3;
+    const TreeRows tr = tree_rows();
+    const int r = tr.r, foot = (tr.rho == 1) ? 1 : 0;
+    const bool jon = tr.on6 && tr.rho < 2;
     const int sole = foot ? 14 : 7;
-    if (lane < 36) {                                               // Xn = X_sole : A = E', B
-        L[A_XN + 36 * 0 + 18 * foot + el] = half ? L[A_XB + 9 * sole + 3 * r + c] : L[A_XE + 9 * sole + 3 * c + r];
-    }
-    const bool jon = lane < 36;
-    const R mh = half ? (R)1 : (R)0;                               // the B half also takes A_n B_f
-    const int fsafe = jon ? foot : 0;
+    R xn[6];
+    {
+        const LV<R> X = L + A_XF + 36 * sole + 6 * r;              // Xn = X_sole
 #pragma unroll
-    for (int s = 0; s < 6; s++) {                                  // straight-line steps, guarded stores
-        WSYNC();
-        const int cur = s & 1;
-        const int f = (fsafe ? 14 : 7) - 1 - s;                    // frame 6..1 / 13..8
-        const LV<R> An = L + A_XN + 36 * cur + 18 * fsafe, Bn = An + 9;
-        const LV<R> E = L + A_XE + 9 * f, Bf = L + A_XB + 9 * f;
-        const LV<R> P1 = half ? Bn : An;                           // picked by address
-        const R xs = P1[3 * r + 2];                                // Xn S (z column)
-        const R t1 = P1[3 * r] * E[3 * c] + P1[3 * r + 1] * E[3 * c + 1] + xs * E[3 * c + 2];   // A_f[k][c] = E[c][k]
-        const R t2 = An[3 * r] * Bf[c] + An[3 * r + 1] * Bf[3 + c] + An[3 * r + 2] * Bf[6 + c];
-        const R val = t1 + mh * t2;
-        if (jon && c == 2) L[A_JL + 72 * foot + 12 * (3 * half + r) + 6 + (5 - s)] = xs;
-        if (jon) L[A_XN + 36 * (cur ^ 1) + 18 * foot + el] = val;
+        for (int c = 0; c < 6; c++) xn[c] = X[c];
     }
-    WSYNC();
-    if (lane < 36) {                                               // base block [A 0; B A]
-        const LV<R> An = L + A_XN + 18 * foot, Bn = An + 9;     // after six steps the product sits in buffer 0
-        if (!half) { L[A_JL + 72 * foot + 12 * r + c] = An[3 * r + c]; L[A_JL + 72 * foot + 12 * r + 3 + c] = 0.0; L[A_JL + 72 * foot + 12 * (3 + r) + 3 + c] = An[3 * r + c]; }
-        else L[A_JL + 72 * foot + 12 * (3 + r) + c] = Bn[3 * r + c];
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int f = sole - 1 - s;                                // frame 6..1 / 13..8
+        if (jon) L[A_JL + 72 * foot + 12 * r + 6 + (5 - s)] = xn[2];                 // Xn S (z column)
+        const LV<R> X = L + A_XF + 36 * f;
+        R A_[9], B_[9];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { A_[3 * k + c] = X[6 * k + c]; B_[3 * k + c] = X[6 * (3 + k) + c]; }
+        R nn[6];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            nn[c] = xn[0] * A_[c] + xn[1] * A_[3 + c] + xn[2] * A_[6 + c] + (xn[3] * B_[c] + xn[4] * B_[3 + c] + xn[5] * B_[6 + c]);
+            nn[3 + c] = xn[3] * A_[c] + xn[4] * A_[3 + c] + xn[5] * A_[6 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) xn[c] = nn[c];
+    }
+    if (jon) {                                                     // base block: row r of the whole product
+        LV<R> o = L + A_JL + 72 * foot + 12 * r;
+#pragma unroll
+        for (int c = 0; c < 6; c++) o[c] = xn[c];
     }
     WSYNC();
     for (int e = lane; e < 144; e += 64) {                         // rotate to world axes
@@ -2914,7 +2930,10 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     STAMP(2);
     if (dbg) {
         for (int e = LANE; e < 336; e += 64) dbg[e] = L[A_T + e];
-        for (int e = LANE; e < 252; e += 64) { dbg[336 + e] = L[A_XE + e]; dbg[672 + e] = L[A_XB + e]; }
+        for (int e = LANE; e < 252; e += 64) {                     // E (= A') and B of every frame, the record layout of the parity tests
+            const int i = e / 9, a = (e % 9) / 3, b = e % 3;
+            dbg[336 + e] = L[A_XF + 36 * i + 6 * b + a]; dbg[672 + e] = L[A_XF + 36 * i + 6 * (3 + a) + b];
+        }
         for (int e = LANE; e < 84; e += 64) dbg[588 + e] = L[A_XP + e];
     }
     STAMP(3);
