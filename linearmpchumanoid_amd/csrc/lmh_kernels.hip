@@ -690,6 +690,7 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
     }
     WSYNC();
     SUBSTAMP(0);
+    WSTAMP(44);
     // local transforms (Khalil DH, Robot.cpp:200-214 + the fixed transforms / offsets of :92-154): every entry is
     // c0 + c1 cos(theta) + c2 sin(theta) with model constants (c0, c1, c2) tabulated once on the host
     // (lcoef, L2-resident); the zero / one coefficients make the fused form bit-identical to the products.
@@ -713,6 +714,7 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
         L[A_T + lane] = val;
     }
     SUBSTAMP(1);
+    WSTAMP(45);
     // Chain products T_dst = T_src Lc: every chain is a path (step s reads what step s - 1 wrote), and lane 12 c + 4 r + col holds entry
     // (r, col) -- the four lanes of a quad are one row of the chain's current transform.  So the recurrence stays in a register and the
     // row of T_src comes from three quad broadcasts (DPP quad_perm) instead of an LDS store / fence / load per step; the local transforms
@@ -750,32 +752,27 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
 // level, no index arithmetic: the coefficients come from the full 6 x 6 images A_XF of X_i = [A 0; B A] (row r contiguous, column r at
 // stride 6, the zero block stored), addressed as (per-lane base) + (compile-time offset of the level).
 // acc += sum_k lane_k(src) * m_k, k = 0..5; needs a full exec mask (wave-uniform control flow).
-__device__ __forceinline__ void bdot6(double &acc, double src, double m0, double m1, double m2, double m3, double m4, double m5)
+// NOP (default): `src` may have been written by the VALU instruction right in front of the block -- the compiler is free to place the
+// instruction that produces an operand there, "VALU write -> DPP read" needs two wait states, and the hazard recognizer does not look
+// into inline asm.  NOP = false only where the source is the accumulator of an earlier block with other blocks in between.
+#define LMH_BD6(op) op " %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" op " %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                    op " %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" op " %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+                    op " %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" op " %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+template <bool NOP = true>
+__device__ __forceinline__ void bdot6(double &acc, double src, const double (&m)[6])
 {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1"                                         // the result may feed a compiler-placed DPP read (the hazard recognizer does not see into the block)
-                 : "+v"(acc) : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5));
+    if constexpr (NOP) asm volatile("s_nop 1\n\t" LMH_BD6("v_fmac_f64_dpp") : "+v"(acc) : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]));
+    else asm volatile(LMH_BD6("v_fmac_f64_dpp") : "+v"(acc) : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]));
 }
-__device__ __forceinline__ void bdot6(float &acc, float src, float m0, float m1, float m2, float m3, float m4, float m5)
+template <bool NOP = true>
+__device__ __forceinline__ void bdot6(float &acc, float src, const float (&m)[6])
 {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(acc) : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5));
+    if constexpr (NOP) asm volatile("s_nop 1\n\t" LMH_BD6("v_fmac_f32_dpp") : "+v"(acc) : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]));
+    else asm volatile(LMH_BD6("v_fmac_f32_dpp") : "+v"(acc) : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]));
 }
-template <typename R>
-__device__ __forceinline__ void bdot6(R &acc, R src, const R (&m)[6]) { bdot6(acc, src, m[0], m[1], m[2], m[3], m[4], m[5]); }
+// Exec-masked LDS stores (s_and_saveexec / ds_write / s_or) cost ~28 cycles each; a store whose address is switched to a dump slot for
+// the lanes that have nothing to write costs one v_cndmask more than a plain one.
+#define P_DUMP (P_TIME + 5)        // never read
 
 // limb rows: frame of (row, depth d) = fb + d with fb = base of the limb; the right-arm row switches to the head frames at depth 5
 struct TreeRows {
@@ -823,6 +820,7 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
         }
     }
     SUBSTAMP(2);
+    WSTAMP(46);
     const int f_lo = (NW == 2 && wid == 1) ? 14 : 1;               // first frame of the E, p loop
     const int f_n = (NW == 1) ? 27 : (wid ? 14 : 13);
     {   // frames 1..27: E = Rp' Ri, p = Rp' pi + (-Rp') pp.  Lane = (frame slot fr < 5, entry el < 12): everything derived from
@@ -863,6 +861,7 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
     }
     WSYNC();
     SUBSTAMP(3);
+    WSTAMP(47);
     const int b_lo = (NW == 2 && wid == 1) ? 14 : 0, b_n = (NW == 1) ? 28 : 14;
     {   // B = (-E') [p]x, entry (a, b) = sg1 E[r1][a] p[j1] + sg2 E[r2][a] p[j2]; lane = (frame slot < 7, entry < 9), seven frames per round
         const int fr = (lane < 63) ? lane / 9 : 0, e9 = lane % 9, a = e9 / 3, bb = e9 % 3;
@@ -881,6 +880,7 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
     }
     WSYNC();
     SUBSTAMP(4);
+    WSTAMP(48);
     if (wid == 0) {
         // persistent copies: T0, T7, T14, X0 = E0 (9) | p0 (3) | B0 (9)
         if (lane < 36) L[P_TB + lane] = L[A_T + 12 * ((lane < 12) ? 0 : (lane < 24) ? 7 : 14) + lane % 12];
@@ -924,27 +924,41 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
         const R s2 = (r == 2) ? (R)1 : (R)0;                       // S = e_z (angular): component 2
         const R ca = (r == 0 || r == 3) ? (R)1 : (R)0, cb = (r == 1 || r == 4) ? (R)-1 : (R)0;   // crm(v) S = (wy, -wx, 0, vy, -vx, 0)
         R pv = bv, pg = bg, p0 = 0;
+        // the coefficients do not depend on the recursion: all seven depths' loads are issued up front (49 doubles), so that the sweep
+        // itself never waits for LDS
+        R xs[7][6], qds[7];
 #pragma unroll
         for (int d = 0; d < 7; d++) {
             const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
             const LV<R> X = L + A_XF + 36 * f + 6 * r;
-            const R x[6] = {X[0], X[1], X[2], X[3], X[4], X[5]};
-            R qd = L[VSRC + 5 + f - tr.adj];
+#pragma unroll
+            for (int k = 0; k < 6; k++) xs[d][k] = X[k];
+            qds[d] = L[VSRC + 5 + f - tr.adj];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < 7; d++) {
+            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
+            const R (&x)[6] = xs[d];
+            R qd = qds[d];
             if (d == 6) qd = (tr.rho < 2) ? (R)0 : qd;             // the soles carry no joint
             if (d == 5) { pv = (tr.rho == 2) ? bv : pv; pg = (tr.rho == 2) ? bg : pg; p0 = (tr.rho == 2) ? (R)0 : p0; }   // the head starts from the base
             R v = s2 * qd;
             bdot6(v, pv, x);
+            asm volatile("s_nop 1");                               // v feeds the lane shifts below
             const R cs = (ca * dpp_row<0x101>(v) + cb * dpp_row<0x111>(v)) * qd;      // row_shl:1 (lane + 1) | row_shr:1 (lane - 1)
             R ag = cs, a0 = cs;
             bdot6(ag, pg, x);
             bdot6(a0, p0, x);
             const bool on = tr.on6 && (d < 5 || tr.rho != 3);      // the left-arm row idles behind its five frames
-            if (on) { L[A_VEL + 6 * f + r] = v; L[A_ACCG + 6 * f + r] = ag; L[A_ACC0 + 6 * f + r] = a0; }
+            const int fs = on ? 6 * f + r : (int)(P_DUMP - A_VEL); // idle lanes: dump slot (frame 27's entries of the three arrays are never read either)
+            L[A_VEL + fs] = v; L[on ? A_ACCG + 6 * f + r : (int)P_DUMP] = ag; L[on ? A_ACC0 + 6 * f + r : (int)P_DUMP] = a0;
             pv = v; pg = ag; p0 = a0;
         }
     }
     WSYNC();
     SUBSTAMP(6);
+    WSTAMP(49);
     // body forces f = I a + v x* (I v), one lane per (body, which)
     {
         const bool fon = lane < 50;
@@ -978,24 +992,35 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
     }
     WSYNC();
     SUBSTAMP(7);
+    WSTAMP(50);
     {   // backward sweep up the limbs: fs_i = f_i + X_c' fs_c (child c), C[joint of i] = fs_i[2]; the limb roots (and the head's) are parked
         // for the base sum.  Depth 6 is the massless sole on the leg rows (skipped) and the head's leaf on the right-arm row.
         R cg = 0, c0 = 0;
+        R ws[7][6], fgs[7], f0s[7];                                // all depths' operands up front (see the forward sweep)
+#pragma unroll
+        for (int d = 6; d >= 0; d--) {
+            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
+            const LV<R> X = L + A_XF + 36 * f + r;                 // column r of X_f
+#pragma unroll
+            for (int k = 0; k < 6; k++) ws[d][k] = X[6 * k];
+            fgs[d] = L[A_FG + 6 * f + r]; f0s[d] = L[A_F0 + 6 * f + r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 6; d >= 0; d--) {
             const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
             const bool active = (d < 5) || (d == 5 && tr.rho != 3) || (d == 6 && tr.rho == 2);
             const bool root = (d == 0) || (d == 5 && tr.rho == 2);
-            const R fg = (R)L[A_FG + 6 * f + r] + cg, f0 = (R)L[A_F0 + 6 * f + r] + c0;
-            if (tr.on6 && active && (lane & 15) == 2) L[CDST + 5 + f - tr.adj] = fg;    // C[5 + act(frame)] (with gravity)
-            const LV<R> X = L + A_XF + 36 * f + r;                 // column r of X_f
-            const R w[6] = {X[0], X[6], X[12], X[18], X[24], X[30]};
+            const R fg = fgs[d] + cg, f0 = f0s[d] + c0;
+            L[(tr.on6 && active && (lane & 15) == 2) ? CDST + 5 + f - tr.adj : (int)P_DUMP] = fg;    // C[5 + act(frame)] (with gravity)
+            const R (&w)[6] = ws[d];
             R ng = 0, n0 = 0;
             bdot6(ng, fg, w);
             bdot6(n0, f0, w);
-            if (tr.on6 && active && root) {                        // A_VEL is dead after the body forces: slot = chain (RL, LL, RA, LA, head)
+            if (d == 0 || d == 5) {                                // A_VEL is dead after the body forces: slot = chain (RL, LL, RA, LA, head)
                 const int ch = (d == 5) ? 4 : tr.rho;
-                L[A_VEL + 12 * ch + r] = ng; L[A_VEL + 12 * ch + 6 + r] = n0;
+                const bool pk = tr.on6 && active && root;
+                L[pk ? A_VEL + 12 * ch + r : (int)P_DUMP] = ng; L[pk ? A_VEL + 12 * ch + 6 + r : (int)P_DUMP] = n0;
             }
             const bool keep = active && !root;
             cg = keep ? ng : (R)0; c0 = keep ? n0 : (R)0;
@@ -1003,6 +1028,7 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
     }
     WSYNC();
     SUBSTAMP(8);
+    WSTAMP(51);
     if (lane < 12) {                                               // base: head, LA, RA, LL, RL (Dynamics.cpp:157-162 order)
         const int w2 = lane / 6, k2 = lane % 6;
         R acc = L[(w2 ? A_F0 : A_FG) + k2];
@@ -1049,7 +1075,7 @@ __device__ __forceinline__ BodyRow6<R> body_row6(int r)
 }
 
 template <typename R>
-__device__ __forceinline__ void phase_crba(LV<R> L)
+__device__ __forceinline__ void phase_crba_rows(LV<R> L)
 {
     const int lane = LANE;
     SUBSTAMP(9);
@@ -1061,65 +1087,74 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
     const int jst = (tr.rho == 0) ? 0 : (tr.rho == 1) ? 6 : (tr.rho == 2) ? 12 : 17;
     R Z[6] = {0, 0, 0, 0, 0, 0};                                   // X' Ic X of the frame folded last (0 in front of a leaf)
     R Fc[7];                                                       // joint columns on their way up, slot = iteration that created them
+    // operands of an iteration (none depends on the recursion): body row (6), A and B of X_f (18, row-uniform addresses), column r of X_f (6).
+    // They are loaded one iteration ahead, in front of the DPP blocks of the running one, so that the recursion never waits for LDS.
+    R mo6[6], A_[9], B_[9], w[6];
+    auto load_ops = [&](int it, R (&m6)[6], R (&a9)[9], R (&b9)[9], R (&w6)[6]) {
+        const int d = 6 - it;
+        const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
+        const LV<R> mo = L + P_MODEL + LMH_BODY_STRIDE * f, X = L + A_XF + 36 * f;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { m6[c] = mo[bs.i[c]]; w6[c] = X[6 * c + r]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { a9[3 * k + c] = X[6 * k + c]; b9[3 * k + c] = X[6 * (3 + k) + c]; }
+    };
+    load_ops(0, mo6, A_, B_, w);
 #pragma unroll
     for (int it = 0; it < 7; it++) {
         const int d = 6 - it;
-        const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;             // legs: frames 6..1 / 13..8 at it 1..6; right-arm row: 26, 25, 19..15; left arm: 24..20 at it 2..6
         const bool active = (it >= 2) || (it == 1 && tr.rho != 3) || (it == 0 && tr.rho == 2);
         const bool root = (it == 6) || (it == 1 && tr.rho == 2);
-        const bool head = (it < 2) && (tr.rho == 2);               // the right-arm row folds the head first
+        const bool head = (it < 2) && (tr.rho == 2);               // the right-arm row folds the head first (frames 26, 25), then 19..15
         const int jbase = head ? 22 : jst, dl = head ? d - 5 : d;  // this frame's joint = jbase + dl
         // ---- Ic = I_f + Z
-        const LV<R> mo = L + P_MODEL + LMH_BODY_STRIDE * f;
         R Ic[6];
 #pragma unroll
-        for (int c = 0; c < 6; c++) Ic[c] = fma(bs.s[c], (R)mo[bs.i[c]], Z[c]);
+        for (int c = 0; c < 6; c++) Ic[c] = fma(bs.s[c], mo6[c], Z[c]);
         Fc[it] = Ic[2];                                            // f = Ic S
-        if (tr.on6 && active && (lane & 15) == 2) L[P_HL + 6 * (jbase + dl) + dl] = Ic[2];       // H(a, a) = f[2]
+        const bool l2 = tr.on6 && active && (lane & 15) == 2;      // the lane that holds f[2]
+        L[l2 ? P_HL + 6 * (jbase + dl) + dl : (int)P_DUMP] = Ic[2];                               // H(a, a) = f[2]
         // ---- Y = Ic X,  X = [A 0; B A]
-        const LV<R> X = L + A_XF + 36 * f;
         R Y[6];
-        {
-            R A_[9], B_[9];
 #pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) { A_[3 * k + c] = X[6 * k + c]; B_[3 * k + c] = X[6 * (3 + k) + c]; }
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                Y[c] = Ic[0] * A_[c] + Ic[1] * A_[3 + c] + Ic[2] * A_[6 + c] + Ic[3] * B_[c] + Ic[4] * B_[3 + c] + Ic[5] * B_[6 + c];
-                Y[3 + c] = Ic[3] * A_[c] + Ic[4] * A_[3 + c] + Ic[5] * A_[6 + c];
-            }
+        for (int c = 0; c < 3; c++) {
+            Y[c] = Ic[0] * A_[c] + Ic[1] * A_[3 + c] + Ic[2] * A_[6 + c] + Ic[3] * B_[c] + Ic[4] * B_[3 + c] + Ic[5] * B_[6 + c];
+            Y[3 + c] = Ic[3] * A_[c] + Ic[4] * A_[3 + c] + Ic[5] * A_[6 + c];
         }
+        const R wc[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+        __builtin_amdgcn_sched_barrier(0);
+        if (it < 6) load_ops(it + 1, mo6, A_, B_, w);              // next iteration's operands: in flight behind the DPP blocks below
+        __builtin_amdgcn_sched_barrier(0);
         // ---- Z = X' Y and the joint columns one frame up: lane r applies column r of X
-        const LV<R> Xc = L + A_XF + 36 * f + r;
-        const R w[6] = {Xc[0], Xc[6], Xc[12], Xc[18], Xc[24], Xc[30]};
         R Zn[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 6; c++) bdot6(Zn[c], Y[c], w);
+        for (int c = 0; c < 6; c++) bdot6(Zn[c], Y[c], wc);
         // columns alive: the head's (slots 0, 1) until the head's root at it 1, the limb's own from its leaf on
 #pragma unroll
         for (int ci = (it >= 2 ? 1 : 0); ci <= it; ci++) {
             R t = 0;
-            bdot6(t, Fc[ci], w);
+            bdot6(t, Fc[ci], wc);
             Fc[ci] = t;
             // the column's joint: created at iteration ci on this row
             const bool chead = ci < 2 && tr.rho == 2 && it < 2;
             const int cd = 6 - ci, cj_l = chead ? cd - 5 : cd, cj = (chead ? 22 : jst) + cj_l;
             const bool exists = (tr.rho == 2) ? (it < 2 ? true : ci >= 2) : (tr.rho == 3 ? ci >= 2 : ci >= 1);
-            if (tr.on6 && active && exists) {
-                if (root) L[P_MTOP + 30 * r + 6 + cj] = t;         // F2 column
-                else if ((lane & 15) == 2) {                       // H(parent joint, column joint) = f[2], both triangles
-                    const int pj_l = dl - 1, pj = jbase + pj_l;
-                    L[P_HL + 6 * pj + cj_l] = t; L[P_HL + 6 * cj + pj_l] = t;
-                }
+            const int pj_l = dl - 1, pj = jbase + pj_l;            // parent joint of this frame (not at a root)
+            if (it == 6) L[(tr.on6 && exists) ? P_MTOP + 30 * r + 6 + cj : (int)P_DUMP] = t;    // every row is at its root: F2 column
+            else {                                                 // H(parent joint, column joint) = f[2], both triangles; the head's root (it 1, right-arm row): F2
+                const bool f2 = (it == 1) && tr.rho == 2;
+                L[(tr.on6 && active && exists && f2) ? P_MTOP + 30 * r + 6 + cj : (l2 && exists && !f2) ? P_HL + 6 * pj + cj_l : (int)P_DUMP] = t;
+                L[(l2 && exists && !f2) ? P_HL + 6 * cj + pj_l : (int)P_DUMP] = t;
             }
         }
-        if (tr.on6 && active && root) {                            // park X' Ic X of the limb root for the base sum (reference order head, LA, RA, LL, RL)
+        if (it == 1 || it == 6) {                                  // park X' Ic X of the limb root for the base sum (reference order head, LA, RA, LL, RL)
             const int slot = (it == 1) ? 0 : 4 - tr.rho;
-            LV<R> o = L + A_XR + 36 * slot + 6 * r;
+            const bool pk = tr.on6 && active && root;
+            const int o = pk ? A_XR + 36 * slot + 6 * r : (int)P_DUMP;
 #pragma unroll
-            for (int c = 0; c < 6; c++) o[c] = Zn[c];
+            for (int c = 0; c < 6; c++) L[pk ? o + c : (int)P_DUMP] = Zn[c];
         }
         const bool keep = active && !root;
 #pragma unroll
@@ -1127,6 +1162,7 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
     }
     WSYNC();
     SUBSTAMP(10);
+    WSTAMP(52);
     if (lane < 6) {                                                // Ic0 = I0 + head + LA + RA + LL + RL (Dynamics.cpp:80-82 order)
         const LV<R> mo = L + P_MODEL;
         R acc[6];
@@ -1144,6 +1180,159 @@ __device__ __forceinline__ void phase_crba(LV<R> L)
     }
     SUBSTAMP(11);
     WSYNC();
+}
+
+// ---- CRBA on the fp64 matrix cores (the fp64 path; the fp32 model-term modes keep the row-per-lane form above).
+// v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4 x 4 x 4 blocks per instruction: block b = (lane >> 2) & 3 is a limb (0 right
+// leg, 1 left leg, 2 right arm preceded by the head, 3 left arm), and with rho = lane >> 4, q = lane & 3 the operand / result maps are
+//     A[i][k] <- lane (rho = k, q = i),   B[k][j] <- lane (rho = k, q = j),   D[i][j] -> lane (rho = i, q = j)
+// (probed on the device: scripts/microbench/mfma4_layout.hip).  A 6 x 6 matrix is four 4 x 4 tiles (zero-padded), one register each.
+// A result (D map) is a B operand as it stands, and fed into the A slot it acts as its TRANSPOSE.  So one level,
+//     Y = M' X  (A = M tiles, B = X tiles),   Z = X' Y  (A = the same X tiles with their indices swapped, B = Y)
+// gives Z = X' M' X: with M = Ic it is (X' Ic X)', with M = Ic' it is X' Ic X -- the stored composite inertia alternates between Ic and its
+// transpose from level to level, and the body inertia added on top is gathered transposed or not to match (the legs are one level out
+// of step with the arms / head, so the parity is (it & 1) ^ leg).  The joint columns F (B operand throughout, no parity) go up one frame
+// with the same X tiles: F <- X' F; the new column Ic S is dropped into its slot by a quad broadcast (M = Ic: column 2 sits at q = 2) or
+// by one more product with a unit matrix (M = Ic': M' e_2 e_slot').  16 + 4..8 + 2 matrix instructions per level replace ~100 VALU ones and
+// run beside the other wave's VALU work.
+__constant__ int c_ib_idx[36] = {0, 1, 2, 12, 11, 10, 3, 4, 5, 11, 12, 9, 6, 7, 8, 10, 9, 12, 12, 11, 10, 12, 12, 12, 11, 12, 9, 12, 12, 12, 10, 9, 12, 12, 12, 12};
+__constant__ double c_ib_sgn[36] = {1, 1, 1, 0, -1, 1, 1, 1, 1, 1, 0, -1, 1, 1, 1, -1, 1, 0, 0, 1, -1, 1, 0, 0, -1, 0, 1, 0, 1, 0, 1, -1, 0, 0, 0, 1};
+// entry (i, j) of the 6 x 6 body inertia [Ibar, [h]x; -[h]x, m 1] (Dynamics.cpp:4-13) = sgn * record[idx]; per lane: tile t = 2 ta + tc holds
+// element (4 ta + rho, 4 tc + q), set s = iteration parity (the gather of set s is transposed when s ^ leg)
+struct IbSel { int i[2][4]; double s[2][4]; };
+__device__ __forceinline__ IbSel ib_select()
+{
+    IbSel g;
+    const int lane = LANE, rho = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int i = 4 * (t >> 1) + rho, j = 4 * (t & 1) + q;
+            const bool ok = (i < 6) && (j < 6), tp = (st != 0) != (b < 2);
+            const int e = ok ? (tp ? 6 * j + i : 6 * i + j) : 0;
+            g.i[st][t] = c_ib_idx[e];
+            const double sv = c_ib_sgn[e];
+            g.s[st][t] = ok ? sv : 0.0;
+        }
+    return g;
+}
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ void phase_crba_mfma(double *L, const IbSel &g)
+{
+    const int lane = LANE;
+    SUBSTAMP(9);
+    const int rho = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
+    const bool leg = b < 2;
+    const int fbB = (b == 0) ? 1 : (b == 1) ? 8 : (b == 2) ? 15 : 20, fbA = (b == 2) ? 20 : fbB;
+    const int jst = (b == 0) ? 0 : (b == 1) ? 6 : (b == 2) ? 12 : 17;
+    for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;        // entries outside a limb's block stay zero
+    // X tiles: element (4 tk + rho, 4 tj + q) of the frame's image; outside the 6 x 6 -> a stored zero of the image (row 0, column 3)
+    int xo[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const int i = 4 * (t >> 1) + rho, j = 4 * (t & 1) + q; xo[t] = (i < 6 && j < 6) ? 6 * i + j : 3; }
+    double Z[4] = {0, 0, 0, 0}, F[4] = {0, 0, 0, 0};              // tiles t = 2 (row tile) + (column tile)
+    double xb[4], ib[4];
+    auto load_ops = [&](int it, double (&x4)[4], double (&i4)[4]) {
+        const int d = 6 - it;
+        const int f = ((d < 5) ? fbB : fbA) + d;
+        const double *X = L + A_XF + 36 * f, *mo = L + P_MODEL + LMH_BODY_STRIDE * f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { x4[t] = X[xo[t]]; i4[t] = mo[g.i[it & 1][t]]; }
+    };
+    load_ops(0, xb, ib);
+#pragma unroll
+    for (int it = 0; it < 7; it++) {
+        const int d = 6 - it;
+        const bool active = (it >= 2) || (it == 1 && b != 3) || (it == 0 && b == 2);
+        const bool root = (it == 6) || (it == 1 && b == 2);
+        const bool head = (it < 2) && (b == 2);                    // block 2 folds the head first (frames 26, 25), then 19..15
+        const int jbase = head ? 22 : jst, dl = head ? d - 5 : d;  // this frame's joint = jbase + dl
+        const bool par = ((it & 1) != 0) != leg;                   // true: the stored matrix is Ic'
+        // ---- stored composite inertia of this frame: body inertia (gathered with the parity) + what the child handed up
+        double M[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) M[t] = fma(g.s[it & 1][t], ib[t], Z[t]);
+        const double x0 = xb[0], x1 = xb[1], x2 = xb[2], x3 = xb[3];
+        __builtin_amdgcn_sched_barrier(0);
+        if (it < 6) load_ops(it + 1, xb, ib);                      // next level's operands: in flight behind the products below
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- new joint column f = Ic S = Ic[:, 2] into slot `it` of F (column tile it >> 2, q = it & 3)
+        {
+            const int tc = it >> 2, qc = it & 3;
+            const bool sel0 = !par && (q == qc);                   // M = Ic: column 2 is (rho, q = 2) of tiles (0,0), (1,0): quad broadcast
+            const double v0 = dpp_row<0xAA>(M[0]), v1 = dpp_row<0xAA>(M[2]);
+            F[tc] = sel0 ? v0 : F[tc]; F[2 + tc] = sel0 ? v1 : F[2 + tc];
+            const double E = (par && rho == 2 && q == qc) ? 1.0 : 0.0;   // M = Ic': (M' e_2) e_slot' as a product (A = M tiles (0, ti): k tile 0 holds k = 2)
+            F[tc] = MFMA4(M[0], E, F[tc]); F[2 + tc] = MFMA4(M[1], E, F[2 + tc]);
+        }
+        L[(active && rho == 2 && q == 2) ? P_HL + 6 * (jbase + dl) + dl : (int)P_DUMP] = M[0];    // H(a, a) = Ic[2][2] (either parity)
+        // ---- Y = M' X (A tile (ti, tk) = M tile (tk, ti)), Zn = X' Y (A tile (ti, tk) = X tile (tk, ti)), Fn = X' F
+        const double y0 = MFMA4(M[2], x2, MFMA4(M[0], x0, 0.0)), y1 = MFMA4(M[2], x3, MFMA4(M[0], x1, 0.0));
+        const double y2 = MFMA4(M[3], x2, MFMA4(M[1], x0, 0.0)), y3 = MFMA4(M[3], x3, MFMA4(M[1], x1, 0.0));
+        double Zn[4], Fn[4];
+        Fn[0] = MFMA4(x2, F[2], MFMA4(x0, F[0], 0.0)); Fn[2] = MFMA4(x3, F[2], MFMA4(x1, F[0], 0.0));
+        if (it >= 4) { Fn[1] = MFMA4(x2, F[3], MFMA4(x0, F[1], 0.0)); Fn[3] = MFMA4(x3, F[3], MFMA4(x1, F[1], 0.0)); }
+        else { Fn[1] = 0.0; Fn[3] = 0.0; }
+        Zn[0] = MFMA4(x2, y2, MFMA4(x0, y0, 0.0)); Zn[1] = MFMA4(x2, y3, MFMA4(x0, y1, 0.0));
+        Zn[2] = MFMA4(x3, y2, MFMA4(x1, y0, 0.0)); Zn[3] = MFMA4(x3, y3, MFMA4(x1, y1, 0.0));
+        // ---- what the columns leave behind: H(parent joint, column joint) = (X' f)[2] on the way, F2 at the limb root
+        {
+            const int pj_l = dl - 1, pj = jbase + pj_l;            // parent joint of this frame (not at a root)
+#pragma unroll
+            for (int tj = 0; tj < ((it >= 4) ? 2 : 1); tj++) {
+                const int ci = 4 * tj + q;                         // column slot = iteration that created the column
+                const bool chead = ci < 2 && b == 2 && it < 2;
+                const int cj_l = chead ? 1 - ci : 6 - ci, cj = (chead ? 22 : jst) + cj_l;
+                const bool exists = (ci <= it) && ((b == 2) ? (it < 2 ? true : ci >= 2) : (b == 3 ? ci >= 2 : ci >= 1));
+                const bool st = active && exists;
+                const bool hrow = st && !root && rho == 2;         // row 2 of X' F
+                L[(st && root) ? P_MTOP + 30 * rho + 6 + cj : hrow ? P_HL + 6 * pj + cj_l : (int)P_DUMP] = Fn[tj];
+                if (it < 6) L[hrow ? P_HL + 6 * cj + pj_l : (int)P_DUMP] = Fn[tj];
+                if (it == 1 || it == 6) L[(st && root && rho < 2) ? P_MTOP + 30 * (4 + rho) + 6 + cj : (int)P_DUMP] = Fn[2 + tj];     // rows 4, 5 of the F2 column
+            }
+        }
+        if (it == 1 || it == 6) {                                  // park X' Ic X of the limb root for the base sum (reference order head, LA, RA, LL, RL)
+            const int slot = (it == 1) ? 0 : 4 - b;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int i = 4 * (t >> 1) + rho, j = 4 * (t & 1) + q;
+                const bool ok = active && root && i < 6 && j < 6;
+                L[ok ? A_XR + 36 * slot + (par ? 6 * i + j : 6 * j + i) : (int)P_DUMP] = Zn[t];     // M = Ic gave (X' Ic X)'
+            }
+        }
+        const bool keep = active && !root;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { Z[t] = (it < 2) ? (keep ? Zn[t] : 0.0) : Zn[t]; F[t] = Fn[t]; }
+    }
+    WSYNC();
+    SUBSTAMP(10);
+    WSTAMP(52);
+    if (lane < 6) {                                                // Ic0 = I0 + head + LA + RA + LL + RL (Dynamics.cpp:80-82 order)
+        const BodyRow6<double> bs = body_row6<double>(lane);
+        const double *mo = L + P_MODEL;
+        double acc[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[c] = bs.s[c] * mo[bs.i[c]];
+#pragma unroll
+        for (int sl = 0; sl < 5; sl++) {
+            const double *o = L + A_XR + 36 * sl + 6 * lane;
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[c] += o[c];
+        }
+        double *mt = L + P_MTOP + 30 * lane;
+#pragma unroll
+        for (int c = 0; c < 6; c++) mt[c] = acc[c];
+    }
+    SUBSTAMP(11);
+    WSYNC();
+}
+// the fp64 path runs on the matrix cores; R = float (mixed / fp32 model terms) keeps the row-per-lane form
+template <typename R>
+__device__ __forceinline__ void phase_crba(LV<R> L, const IbSel &g)
+{
+    if constexpr (std::is_same_v<R, double>) phase_crba_mfma(L.p, g);
+    else phase_crba_rows<R>(L);
 }
 
 // Kinematics::feetJacobian / frameJacobian (invKinematics.cpp:72-149), chain products in the
@@ -1164,30 +1353,31 @@ __device__ __forceinline__ void phase_jacobian(LV<R> L)
 #pragma unroll
         for (int c = 0; c < 6; c++) xn[c] = X[c];
     }
-#pragma unroll
-    for (int s = 0; s < 6; s++) {
-        const int f = sole - 1 - s;                                // frame 6..1 / 13..8
-        if (jon) L[A_JL + 72 * foot + 12 * r + 6 + (5 - s)] = xn[2];                 // Xn S (z column)
+    R A_[9], B_[9];
+    auto load_x = [&](int f, R (&a9)[9], R (&b9)[9]) {
         const LV<R> X = L + A_XF + 36 * f;
-        R A_[9], B_[9];
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) { A_[3 * k + c] = X[6 * k + c]; B_[3 * k + c] = X[6 * (3 + k) + c]; }
+            for (int c = 0; c < 3; c++) { a9[3 * k + c] = X[6 * k + c]; b9[3 * k + c] = X[6 * (3 + k) + c]; }
+    };
+    load_x(sole - 1, A_, B_);
+#pragma unroll
+    for (int s = 0; s < 6; s++) {                                  // frame 6..1 / 13..8; the next frame's X is loaded while this one is applied
+        L[jon ? A_JL + 72 * foot + 12 * r + 6 + (5 - s) : (int)P_DUMP] = xn[2];      // Xn S (z column)
         R nn[6];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             nn[c] = xn[0] * A_[c] + xn[1] * A_[3 + c] + xn[2] * A_[6 + c] + (xn[3] * B_[c] + xn[4] * B_[3 + c] + xn[5] * B_[6 + c]);
             nn[3 + c] = xn[3] * A_[c] + xn[4] * A_[3 + c] + xn[5] * A_[6 + c];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 5) load_x(sole - 2 - s, A_, B_);
 #pragma unroll
         for (int c = 0; c < 6; c++) xn[c] = nn[c];
     }
-    if (jon) {                                                     // base block: row r of the whole product
-        LV<R> o = L + A_JL + 72 * foot + 12 * r;
 #pragma unroll
-        for (int c = 0; c < 6; c++) o[c] = xn[c];
-    }
+    for (int c = 0; c < 6; c++) L[jon ? A_JL + 72 * foot + 12 * r + c : (int)P_DUMP] = xn[c];      // base block: row r of the whole product
     WSYNC();
     for (int e = lane; e < 144; e += 64) {                         // rotate to world axes
         const int ft = e / 72, rr = (e % 72) / 12, col = e % 12, r3 = rr % 3, o = (rr / 3) * 3;
@@ -2894,6 +3084,8 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     STAMP(0);
     WSTAMP(0);
     const RefPrefetch pre = prefetch_refs(P, inst, t);
+    IbSel ibsel;                                                   // gather tables of the matrix-core CRBA: constant-memory loads, issued long before their use
+    if constexpr (std::is_same_v<R, double>) { if (NW == 1 || wid == 1) ibsel = ib_select(); }
     if (NW == 2 && wid == 1) {
         // while wave 0 runs the forward kinematics: K_f^-1 of the free set the cone solve will start from (same rule as
         // phase_qp: previous active set minus the coefficients of feet out of support); scratch: the CRBA parking area
@@ -2942,7 +3134,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
         phase_newton_euler<R>(L);
         if (plant) phase_newton_euler<R, true>(L);                 // the plant's velocity products at the CURRENT velocity (before CRBA reuses the scratch)
         STAMP(4);
-        phase_crba<R>(L);
+        phase_crba<R>(L, ibsel);
         STAMP(5);
         phase_jacobian<R>(L);
     } else {
@@ -2952,7 +3144,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
             STAMP(4);
             phase_jacobian<R>(L);
         }
-        else phase_crba<R>(L);
+        else phase_crba<R>(L, ibsel);
         STAMP(5);                                                  // per wave: end of its share of the tree phases
     }
     WSTAMP(5);
