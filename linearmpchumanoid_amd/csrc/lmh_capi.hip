@@ -243,6 +243,8 @@ static void fill_params(lmh_handle *h)
     P.kp_feet = c.kp_feet; P.kd_feet = c.kd_feet;
     P.w_com_lin = c.w_com_lin; P.w_com_ang = c.w_com_ang; P.w_base_pos = c.w_base_pos; P.w_base_ang = c.w_base_ang;
     P.w_joints = c.w_joints; P.w_force = c.w_force; P.w_foot = c.w_foot; P.eps_coeff = c.eps_coeff;
+    P.inv_w_base_pos = 1.0 / c.w_base_pos; P.inv_w_base_ang = 1.0 / c.w_base_ang; P.inv_w_joints = 1.0 / c.w_joints;
+    P.inv_w_com_lin = 1.0 / c.w_com_lin; P.inv_w_foot = 1.0 / c.w_foot;
     const double md = h->mpc_dt;                                     // mpcLinearPendulum.cpp:45-47 with the Mpc3dLip ctor's dt
     P.a00 = 1; P.a01 = md; P.a10 = 0; P.a11 = 1; P.b0 = (md * md) / 2; P.b1 = md;
 }

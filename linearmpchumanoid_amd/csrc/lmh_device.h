@@ -38,6 +38,7 @@ struct LmhDevParams {
     double kp_joints, kd_joints, kp_mom, kd_mom, kp_feet, kd_feet;
     double w_com_lin, w_com_ang, w_base_pos, w_base_ang, w_joints, w_force, w_foot;
     double eps_coeff;
+    double inv_w_base_pos, inv_w_base_ang, inv_w_joints, inv_w_com_lin, inv_w_foot;   // 1.0 / weight, divided once on the host (the same IEEE quotient the kernels used to form per evaluation)
     double contact_k, contact_d, contact_dt, contact_mu;
     double a00, a01, a10, a11, b0, b1;   // LIPM A, B (mpcLinearPendulum.cpp:45-47)
     // ---- foot reference polynomials (shared), ascending powers

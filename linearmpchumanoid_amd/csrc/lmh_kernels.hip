@@ -1483,51 +1483,56 @@ __device__ __forceinline__ void refs_prepare(double *L, const LmhDevParams &P, i
 // The references form two independent chains: (A) AG, AGpqp -> momentum -> MPC -> PDMomentumAcc needs the mass
 // matrix; (B) foot velocities, PDJointsAcc -> PDFeetAcc needs the Jacobian.  NW = 1 interleaves them step by
 // step in one wave; NW = 2 gives chain A to wave 1 and chain B to wave 0 (the caller joins them).
-__device__ __forceinline__ void refs_ag(double *L, double mass)
+// `ang`: also the angular-momentum rows 0..2 (AG_ang, needed only when the angular-momentum weight is set or a debug record is dumped:
+// with w_com_ang = 0 -- the reference's literal -- neither the QP nor any output reads them, and they are the expensive half: 6-term
+// entries with three divisions by the mass each)
+__device__ __forceinline__ void refs_ag(double *L, double mass, bool ang)
 {
     const int lane = LANE;
-    for (int e = lane; e < 180; e += 64) {
-        const int r = e / 30, c = e % 30;
-        const double *T0 = L + P_TB, *Mt = L + P_MTOP + c;
-        double val;
-        if (r < 3) {
+    const double *T0 = L + P_TB;
+    for (int e = 90 + lane; e < 180; e += 64) {                    // rows 3..5: R0 Mt_lin
+        const int a = e / 30 - 3, c = e % 30;
+        const double *Mt = L + P_MTOP + c;
+        L[P_AG + e] = T0[4 * a] * Mt[90] + T0[4 * a + 1] * Mt[120] + T0[4 * a + 2] * Mt[150];
+    }
+    if (ang) {                                                     // wave-uniform
+        for (int e = lane; e < 90; e += 64) {
+            const int r = e / 30, c = e % 30;
+            const double *Mt = L + P_MTOP + c;
             const double p0 = L[P_MTOP + 30 * 2 + 4] / mass, p1 = L[P_MTOP + 30 * 0 + 5] / mass, p2 = L[P_MTOP + 30 * 1 + 3] / mass;
             // U = -(R0 [p1G]x): U[r][0] = -(R[r][1] p2 - R[r][2] p1) ...
             const double R0 = T0[4 * r], R1 = T0[4 * r + 1], R2 = T0[4 * r + 2];
             const double u0 = -(R1 * p2 + R2 * (-p1)), u1 = -(R0 * (-p2) + R2 * p0), u2 = -(R0 * p1 + R1 * (-p0));
-            val = R0 * Mt[0] + R1 * Mt[30] + R2 * Mt[60] + u0 * Mt[90] + u1 * Mt[120] + u2 * Mt[150];
-        } else {
-            const int a = r - 3;
-            val = T0[4 * a] * Mt[90] + T0[4 * a + 1] * Mt[120] + T0[4 * a + 2] * Mt[150];
+            L[P_AG + e] = R0 * Mt[0] + R1 * Mt[30] + R2 * Mt[60] + u0 * Mt[90] + u1 * Mt[120] + u2 * Mt[150];
         }
-        L[P_AG + e] = val;
     }
 }
 // AGpqp = X1G Cg[0:6] (Dynamics.cpp:103-121): needs the mass matrix (CRBA) AND the gravity-free bias (Newton-Euler); on the two-wave
 // schedule those come from different waves, so this piece runs after their join (phase_qp), not inside the reference chains
-__device__ __forceinline__ void refs_agpqp(double *L, double mass)
+__device__ __forceinline__ void refs_agpqp(double *L, double mass, bool ang)
 {
     const int lane = LANE;
     if (lane < 6) {
         const double *T0 = L + P_TB, *cg = L + P_CG;
         const int r = lane % 3;
-        double val;
-        if (lane < 3) {
+        double val = 0.0;
+        if (lane < 3) { if (ang) {
             const double p0 = L[P_MTOP + 30 * 2 + 4] / mass, p1 = L[P_MTOP + 30 * 0 + 5] / mass, p2 = L[P_MTOP + 30 * 1 + 3] / mass;
             const double R0 = T0[4 * r], R1 = T0[4 * r + 1], R2 = T0[4 * r + 2];
             const double u0 = -(R1 * p2 + R2 * (-p1)), u1 = -(R0 * (-p2) + R2 * p0), u2 = -(R0 * p1 + R1 * (-p0));
             val = R0 * cg[0] + R1 * cg[1] + R2 * cg[2] + u0 * cg[3] + u1 * cg[4] + u2 * cg[5];
-        } else val = T0[4 * r] * cg[3] + T0[4 * r + 1] * cg[4] + T0[4 * r + 2] * cg[5];
-        L[P_AGPQP + lane] = val;
+        } } else val = T0[4 * r] * cg[3] + T0[4 * r + 1] * cg[4] + T0[4 * r + 2] * cg[5];
+        L[P_AGPQP + lane] = val;                                   // the angular entries are 0 when nothing reads them (see refs_ag)
     }
 }
-__device__ __forceinline__ void refs_momentum(double *L, double mass)
+__device__ __forceinline__ void refs_momentum(double *L, double mass, bool ang)
 {
     const int lane = LANE;
     if (lane < 6) {                                                // h = AG vhat (fresh velocity)
+        const int row = (ang || lane >= 3) ? lane : 3;             // the angular rows of AG are not formed when nothing reads them
         double s = 0.0;
-        for (int c = 0; c < 30; c++) s += L[P_AG + 30 * lane + c] * L[P_VHN + c];
-        if (lane < 3) L[P_ANGM + lane] = s; else L[P_COMV + lane - 3] = s / mass;
+        for (int c = 0; c < 30; c++) s += L[P_AG + 30 * row + c] * L[P_VHN + c];
+        if (lane < 3) L[P_ANGM + lane] = ang ? s : 0.0; else L[P_COMV + lane - 3] = s / mass;
     }
 }
 __device__ __forceinline__ void refs_vfoot_pdjoints(double *L, const LmhDevParams &P)
@@ -1623,7 +1628,7 @@ __device__ __forceinline__ void refs_pd_feet(double *L, const LmhDevParams &P, i
 }
 
 template <int NW>
-__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre, int wid, int *k_out, int *phase_out)
+__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre, int wid, int *k_out, int *phase_out, bool ang)
 {
     int flags = 0;
     const double mass = L[P_MODEL + 392];
@@ -1631,11 +1636,11 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
     *k_out = pre.k; *phase_out = pre.ph;
     if (pre.k < 0 || pre.k + P.horizon >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;    // on every wave (wave 0 reports)
     if constexpr (NW == 1) {
-        refs_ag(L, mass);
-        refs_agpqp(L, mass);
+        refs_ag(L, mass, ang);
+        refs_agpqp(L, mass, ang);
         WSYNC();
         SUBSTAMP(12);
-        refs_momentum(L, mass);
+        refs_momentum(L, mass, ang);
         refs_vfoot_pdjoints(L, P);
         WSYNC();
         SUBSTAMP(13);
@@ -1646,9 +1651,9 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         refs_pd_feet(L, P, inst, t, pre.k);
         WSYNC();
     } else if (wid == 1) {                                         // chain A
-        refs_ag(L, mass);
+        refs_ag(L, mass, ang);
         WSYNC();
-        refs_momentum(L, mass);
+        refs_momentum(L, mass, ang);
         WSYNC();
         flags |= refs_mpc(L, P, inst, pre, &zcom);
         WSYNC();
@@ -2380,7 +2385,7 @@ __device__ __forceinline__ v4d mfma_ptr(const double *a0, const double *b0)
 __device__ __forceinline__ void qp_prefill15(double *L, const LmhDevParams &P)
 {
     const int lane = LANE;
-    const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;
+    const double idp = P.inv_w_base_pos, ida = P.inv_w_base_ang, idj = P.inv_w_joints;
 #pragma unroll
     for (int it = 0; it < 6; it++) {
         const int e = lane + 64 * it, r = e >> 5, c = e & 31, o = 34 * r + c;
@@ -2407,7 +2412,7 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
     const int lane = LANE;
     int flags = 0;
     constexpr int nU = 15;
-    const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
+    const double idp = P.inv_w_base_pos, ida = P.inv_w_base_ang, idj = P.inv_w_joints;   // D^-1 (wave-uniform)
     const int tr = lane & 15, tq = lane >> 4;                      // fragment row / k-quarter; result rows tq + 4 reg, column tr
     // ---- fills: U, U D^-1 (padded 16 x 32; row order: 12 Jacobian rows, 3 linear-momentum rows, one zero row), bp'' (8 x 32), weights
     if constexpr (NW == 1) qp_prefill15(L, P);                     // NW = 2: wave 0 has already written the Jacobian rows (controller_eval)
@@ -2435,7 +2440,7 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
             const double om = (rr < 6) ? P.w_com_lin : P.w_foot;
             const double beta = (rr < 6) ? (L[P_AGPQP + rr] - L[P_HREF + rr]) : (L[P_JPQP + rr - 6] - L[P_FREF + rr - 6]);
             L[Q_OB + lane] = in ? om * beta : 0.0;
-            L[Q_OB + 16 + lane] = in ? 1.0 / om : 1.0;
+            L[Q_OB + 16 + lane] = in ? ((rr < 6) ? P.inv_w_com_lin : P.inv_w_foot) : 1.0;
             L[Q_OB + 32 + lane] = in ? beta : 0.0;
         }
         if (lane >= 32) L[Q_ZERO + lane - 32] = 0.0;
@@ -2616,7 +2621,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
     int flags = 0;
     // ---- rows of U = [AG ; J] with weights Om, skipping zero-weight rows
     constexpr int nU = NU, r0 = 18 - NU;
-    const double idp = 1.0 / P.w_base_pos, ida = 1.0 / P.w_base_ang, idj = 1.0 / P.w_joints;   // D^-1 (wave-uniform)
+    const double idp = P.inv_w_base_pos, ida = P.inv_w_base_ang, idj = P.inv_w_joints;   // D^-1 (wave-uniform)
     const int tr = lane & 15, tq = lane >> 4;                      // MFMA result: rows tq + 4 reg, column tr
     for (int e = lane + 64 * wid; e < nU * 30; e += 64 * NW) {
         const int r = r0 + e / 30, c = e % 30;
@@ -2819,7 +2824,7 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
 {
     const int lane = LANE;
     int flags;
-    if (NW == 2 && wid == 0) { refs_agpqp(L, L[P_MODEL + 392]); WSYNC(); }     // first point where both M (wave 1) and Cg (wave 0) exist
+    if (NW == 2 && wid == 0) { refs_agpqp(L, L[P_MODEL + 392], (P.w_com_ang != 0.0) || (dbgp != nullptr)); WSYNC(); }     // first point where both M (wave 1) and Cg (wave 0) exist
     if constexpr (F32) {
         if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
         flags = qp_setup_f32(L, P);
@@ -3152,7 +3157,8 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     // already published; AGpqp, which needs both, is formed after the next join (phase_qp)
     WSTAMP(6);
     STAMP(6);
-    flags |= phase_refs<NW>(L, P, inst, t, pre, wid, k_out, &ph);
+    const bool ang = (P.w_com_ang != 0.0) || (dbg != nullptr);     // angular-momentum rows: only when weighted (or dumped)
+    flags |= phase_refs<NW>(L, P, inst, t, pre, wid, k_out, &ph, ang);
     if (NW == 2 && wid == 0 && P.w_com_ang == 0.0 && !QF32) qp_prefill15(L, P);      // ahead of the join: wave 1's chain is the longer one
     WSTAMP(7);
     bsync<NW>();
