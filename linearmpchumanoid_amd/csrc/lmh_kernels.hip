@@ -3081,7 +3081,7 @@ __device__ __forceinline__ void phase_outputs_qdd(double *L, int a_src = P_A)
 // are wave-local.  Wave 1 never touches P_Q / P_V / the QP scratch after its last bsync, so wave 0 may run ahead
 // into the next evaluation's forward kinematics.
 template <int NW, typename R, bool QF32 = false>
-__device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg)
+__device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg, bool need_tau = true)
 {
     int flags = 0, ph = 0;
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
@@ -3167,8 +3167,9 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     flags |= phase_qp<NW, QF32>(L, P, ph, wid, Fmask, iters_out, dbg);
     STAMP(8);
     if (plant && (NW == 1 || wid == 0)) phase_plant(L, P);         // the torques drive a plant instead of being thrown away (main.cpp:118-121)
-    if constexpr (NW == 1) { phase_outputs_tau(L); phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); }
-    else { if (wid == 0) phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); else phase_outputs_tau(L); }
+    // need_tau (wave-uniform): the integrator never reads the torques -- the rollout asks for them at the k4 stage only (log, final record)
+    if constexpr (NW == 1) { if (need_tau) phase_outputs_tau(L); phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); }
+    else { if (wid == 0) phase_outputs_qdd(L, plant ? (int)PL_AP : (int)P_A); else if (need_tau) phase_outputs_tau(L); }
     WSTAMP(28);
     STAMP(9);
     if (dbg) {
@@ -3354,7 +3355,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             }
             const LmhDevParams *Pe = Pg;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
-            flags |= controller_eval<2, R, QF32>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr);
+            flags |= controller_eval<2, R, QF32>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
                 // xdot (apps/offline/main.cpp:107-121)
