@@ -1409,63 +1409,50 @@ __device__ __forceinline__ double jdense(const double *L, int row, int col)
 // Dynamics::centroidalMatrixAndBias (Dynamics.cpp:103-121), Robot::computeComMomentum
 // (Robot.cpp:300-310), Mpc3dLip::compute (mpcLinearPendulum.cpp:78-109), PD references
 // (controller.cpp:296-386).
-// Reference samples of one evaluation, fetched from HBM/L2 at the top of controller_eval so that their latency
-// hides behind the kinematics: lane i holds zmp[k + i] (first 64 samples of the preview window).
-struct RefPrefetch { int k; double zx, zy, xs; int ph, seg; };
-__device__ __forceinline__ RefPrefetch prefetch_refs(const LmhDevParams &P, int inst, double t)
-{
-    RefPrefetch r;
-    r.k = (int)(t / P.mpc_dt);                                     // mpcLinearPendulum.cpp:92 (fp64, same op order; dt_ = the Mpc3dLip ctor's dt)
-    int kk = r.k + LANE;
-    kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
-    r.zx = P.zmpx[kk]; r.zy = P.zmpy[kk];
-    r.xs = P.xscale ? P.xscale[inst] : 1.0;                        // walking extension: per-instance step length
-    r.ph = 0;
-    const int k0 = (r.k < 0) ? 0 : (r.k >= P.n_samples ? P.n_samples - 1 : r.k);
-    if (P.phase) r.ph = P.phase[k0];
-    r.seg = (P.n_seg > 0) ? (int)P.seg_of_sample[k0] : 0;          // walking: swing-polynomial segment of sample k (its coefficients are loaded by refs_prepare)
-    return r;
-}
-
-// References that depend on the clock only (preview window of the ZMP, foot polynomials): evaluated before / beside the
-// kinematics (NW = 2: by the helper wave while wave 0 runs the forward kinematics).
-__device__ __forceinline__ void refs_prepare(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre)
+// References that depend on the clock only: the preview window of the ZMP (through the gain row), the support phase and the foot
+// polynomials.  Everything but the polynomial VALUES is a function of the preview index k = int(t / mpc_dt) alone, and k stays put for
+// mpc_dt / dt ticks x 4 stages (40 evaluations at 1 kHz / 10 ms): the robot keeps {k, phase, sum K zmp, the swing segment's coefficients
+// already scaled by its step length, the segment's t0} in LDS and goes back to HBM / L2 only when k moves.  One wave maintains the cache
+// (NW = 2: the helper wave, beside the forward kinematics); the other reads k / phase after the first join.
+#define P_RK (P_TIME + 1)          // cached preview index (as a double; set to -2^30 when a robot is loaded)
+#define P_RPH (P_TIME + 2)         // support phase of sample k
+#define P_RXS (P_TIME + 3)         // the robot's step-length scale (lmh_set_xscale), 1 without
+#define P_RT0 (P_POLY + 54)        // start time of the cached swing segment (0 without segments)
+__device__ __forceinline__ void refs_prepare(double *L, const LmhDevParams &P, int inst, double t)
 {
     const int lane = LANE;
-    const int N = P.horizon, k = pre.k;
-    {
+    const int N = P.horizon;
+    const int k = (int)(t / P.mpc_dt);                             // mpcLinearPendulum.cpp:92 (fp64, same op order; dt_ = the Mpc3dLip ctor's dt)
+    if (k != __builtin_amdgcn_readfirstlane((int)L[P_RK])) {       // wave-uniform: the preview index moved
         const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
+        const int ns = P.n_samples;
         double sx = 0.0, sy = 0.0;
-        for (int i = lane; i <= N; i += 64) {
-            double zxv = pre.zx, zyv = pre.zy;
-            if (i >= 64) {                                         // only N = 64 reaches a second round
-                int kk = k + i;
-                kk = (kk < 0) ? 0 : (kk >= P.n_samples ? P.n_samples - 1 : kk);
-                zxv = P.zmpx[kk]; zyv = P.zmpy[kk];
-            }
+        for (int i = lane; i <= N; i += 64) {                      // only N = 64 reaches a second round
+            int kk = k + i;
+            kk = (kk < 0) ? 0 : (kk >= ns ? ns - 1 : kk);
             const double K = (N <= MPC_LDS_MAXN) ? L[P_MPCK + i] : mp[i];
-            sx += K * zxv; sy += K * zyv;
+            sx += K * P.zmpx[kk]; sy += K * P.zmpy[kk];
+        }
+        const int k0 = (k < 0) ? 0 : (k >= ns ? ns - 1 : k);
+        const int ph = P.phase ? (int)P.phase[k0] : 0;
+        if (P.n_seg > 0) {                                         // walking extension: swing-polynomial segment of sample k, x axis in units of the step length
+            const double *sg = P.segs + (size_t)LMH_SEG_STRIDE * (int)P.seg_of_sample[k0];
+            const double xs = L[P_RXS];
+            if (lane < 48) L[P_POLY + lane] = sg[1 + lane] * (((lane % 24) < 8) ? xs : 1.0);
+            else if (lane < 54) L[P_POLY + lane] = 8.0;
+            else if (lane == 54) L[P_RT0] = sg[0];
         }
         sx = wave_sum(sx); sy = wave_sum(sy);
-        if (lane == 0) { L[P_PRE] = sx; L[P_PRE + 1] = sy; }
+        if (lane == 0) { L[P_PRE] = sx; L[P_PRE + 1] = sy; L[P_RK] = (double)k; L[P_RPH] = (double)ph; }
+        WSYNC();
     }
     if (lane >= 16 && lane < 22) {                                 // polyval / polyder of the foot references (controller.cpp:355-386)
         const int ft = (lane - 16) / 3, ax = (lane - 16) % 3;
         double co[8];
-        int n;
-        double tl = t;
-        if (P.n_seg > 0) {                                         // walking extension: segment of preview index k
-            const double *sg = P.segs + (size_t)LMH_SEG_STRIDE * pre.seg;
-            const double sc = (ax == 0 && P.xscale) ? P.xscale[inst] : 1.0;
-            tl = t - sg[0];
+        const double tl = t - L[P_RT0];
 #pragma unroll
-            for (int i = 0; i < 8; i++) co[i] = sg[1 + 24 * ft + 8 * ax + i] * sc;
-            n = 8;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) co[i] = L[P_POLY + 24 * ft + 8 * ax + i];
-            n = (int)L[P_POLY + 48 + 3 * ft + ax];
-        }
+        for (int i = 0; i < 8; i++) co[i] = L[P_POLY + 24 * ft + 8 * ax + i];
+        const int n = (int)L[P_POLY + 48 + 3 * ft + ax];
         double pv = 0, xp = 1;
 #pragma unroll
         for (int i = 0; i < 8; i++) if (i < n) { pv += co[i] * xp; xp *= tl; }
@@ -1552,13 +1539,12 @@ __device__ __forceinline__ void refs_vfoot_pdjoints(double *L, const LmhDevParam
         L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
     }
 }
-__device__ __forceinline__ int refs_mpc(double *L, const LmhDevParams &P, int inst, const RefPrefetch &pre, double *zcom_out)
+__device__ __forceinline__ int refs_mpc(double *L, const LmhDevParams &P, int inst, int k, double *zcom_out)
 {
     const int lane = LANE;
     int flags = 0;
     // ---- MPC: u0 = -K (Px x_k - z[k : k+N+1])
     const int N = P.horizon;
-    const int k = pre.k;
     if (k < 0 || k + N >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;
     const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
     const double zcom = mp[3 * (N + 1)];
@@ -1567,7 +1553,7 @@ __device__ __forceinline__ int refs_mpc(double *L, const LmhDevParams &P, int in
         // are prepared early (refs_prepare / load_common)
         const double cxp = L[P_COM], cyp = L[P_COM + 1], vxp = L[P_COMV], vyp = L[P_COMV + 1];
         const double kp0 = L[P_PRE + 2], kp1 = L[P_PRE + 3];
-        const double sx = (kp0 * cxp + kp1 * vxp) - pre.xs * L[P_PRE];
+        const double sx = (kp0 * cxp + kp1 * vxp) - L[P_RXS] * L[P_PRE];
         const double sy = (kp0 * cyp + kp1 * vyp) - L[P_PRE + 1];
         const double ux = -sx, uy = -sy;
         if (lane == 0) {
@@ -1628,13 +1614,14 @@ __device__ __forceinline__ void refs_pd_feet(double *L, const LmhDevParams &P, i
 }
 
 template <int NW>
-__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, const RefPrefetch &pre, int wid, int *k_out, int *phase_out, bool ang)
+__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, int wid, int *k_out, int *phase_out, bool ang)
 {
     int flags = 0;
     const double mass = L[P_MODEL + 392];
     double zcom = 0.0;
-    *k_out = pre.k; *phase_out = pre.ph;
-    if (pre.k < 0 || pre.k + P.horizon >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;    // on every wave (wave 0 reports)
+    const int k = __builtin_amdgcn_readfirstlane((int)L[P_RK]);   // the clock-only references of this evaluation (refs_prepare, before the first join)
+    *k_out = k; *phase_out = __builtin_amdgcn_readfirstlane((int)L[P_RPH]);
+    if (k < 0 || k + P.horizon >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;    // on every wave (wave 0 reports)
     if constexpr (NW == 1) {
         refs_ag(L, mass, ang);
         refs_agpqp(L, mass, ang);
@@ -1644,25 +1631,25 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
         refs_vfoot_pdjoints(L, P);
         WSYNC();
         SUBSTAMP(13);
-        flags |= refs_mpc(L, P, inst, pre, &zcom);
+        flags |= refs_mpc(L, P, inst, k, &zcom);
         WSYNC();
         SUBSTAMP(14);
         refs_pd_momentum(L, P, mass, zcom);
-        refs_pd_feet(L, P, inst, t, pre.k);
+        refs_pd_feet(L, P, inst, t, k);
         WSYNC();
     } else if (wid == 1) {                                         // chain A
         refs_ag(L, mass, ang);
         WSYNC();
         refs_momentum(L, mass, ang);
         WSYNC();
-        flags |= refs_mpc(L, P, inst, pre, &zcom);
+        flags |= refs_mpc(L, P, inst, k, &zcom);
         WSYNC();
         refs_pd_momentum(L, P, mass, zcom);
         WSYNC();
     } else {                                                       // chain B
         refs_vfoot_pdjoints(L, P);
         WSYNC();
-        refs_pd_feet(L, P, inst, t, pre.k);
+        refs_pd_feet(L, P, inst, t, k);
         WSYNC();
     }
     return flags;
@@ -3088,15 +3075,17 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
 #define STAMP(i) do { if (dbg && LANE == 0) dbg[(wid ? 3950 : 4000) + (i)] = (double)clock64(); } while (0)   // wave 1 (diagnostic two-wave debug kernel): 3950..
     STAMP(0);
     WSTAMP(0);
-    const RefPrefetch pre = prefetch_refs(P, inst, t);
     IbSel ibsel;                                                   // gather tables of the matrix-core CRBA: constant-memory loads, issued long before their use
     if constexpr (std::is_same_v<R, double>) { if (NW == 1 || wid == 1) ibsel = ib_select(); }
     if (NW == 2 && wid == 1) {
-        // while wave 0 runs the forward kinematics: K_f^-1 of the free set the cone solve will start from (same rule as
-        // phase_qp: previous active set minus the coefficients of feet out of support); scratch: the CRBA parking area
+        // while wave 0 runs the forward kinematics: the clock-only references, then K_f^-1 of the free set the cone solve will start from
+        // (same rule as phase_qp: previous active set minus the coefficients of feet out of support); scratch: the CRBA parking area
+        refs_prepare(L, P, inst, t);
+        WSYNC();
+        const int ph0 = __builtin_amdgcn_readfirstlane((int)L[P_RPH]);
         unsigned forced = 0u;
-        if (pre.ph == LMH_PHASE_LEFT || pre.ph == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;
-        if (pre.ph == LMH_PHASE_RIGHT || pre.ph == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
+        if (ph0 == LMH_PHASE_LEFT || ph0 == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;
+        if (ph0 == LMH_PHASE_RIGHT || ph0 == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
         const unsigned Fpub = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)L[P_KF]);
         const unsigned F0 = (P.warm_start ? Fpub : 0xFFFFFFFFu) & ~forced;
         int st = 0;
@@ -3108,11 +3097,10 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
             st = thin ? 2 : (kinv_compute(L, F0, L + P_KI, L + A_XR) ? 2 : 1);
         }
         if (LANE == 0) { L[P_KF + 1] = (double)F0; L[P_KF + 2] = (double)st; }
-        refs_prepare(L, P, inst, t, pre);
     }
     if constexpr (NW == 1) {                                       // single-wave schedule: no K^-1 prepared; references first
         if (LANE == 0) L[P_KF + 2] = 0.0;
-        refs_prepare(L, P, inst, t, pre);
+        refs_prepare(L, P, inst, t);
         WSYNC();
     }
     if (wid == 0) phase_fk<R>(L, P.gcol + 228);
@@ -3158,7 +3146,7 @@ __device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P,
     WSTAMP(6);
     STAMP(6);
     const bool ang = (P.w_com_ang != 0.0) || (dbg != nullptr);     // angular-momentum rows: only when weighted (or dumped)
-    flags |= phase_refs<NW>(L, P, inst, t, pre, wid, k_out, &ph, ang);
+    flags |= phase_refs<NW>(L, P, inst, t, wid, k_out, &ph, ang);
     if (NW == 2 && wid == 0 && P.w_com_ang == 0.0 && !QF32) qp_prefill15(L, P);      // ahead of the join: wave 1's chain is the longer one
     WSTAMP(7);
     bsync<NW>();
@@ -3223,6 +3211,10 @@ __device__ __forceinline__ void load_common(double *L, const LmhDevParams &P, in
         L[P_POLY + LANE] = (double)n;
     }
     load_tables(L);
+    if (LANE == 0) {                                               // clock-only reference cache (refs_prepare): empty
+        L[P_RK] = -1073741824.0; L[P_RPH] = 0.0; L[P_RT0] = 0.0;
+        L[P_RXS] = P.xscale ? P.xscale[inst] : 1.0;                // walking extension: per-instance step length
+    }
     {
         const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
         const int N = P.horizon;
