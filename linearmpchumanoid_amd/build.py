@@ -39,6 +39,23 @@ def build(force=False, verbose=False):
     return SO
 
 
+def build_variant(name, flags, force=False, verbose=False):
+    """Experiment / checker builds of the same sources into liblmh_hip_var_<name>.so (never the shipped library; loaded with
+    LMH_VARIANT=<name>).  `poison` (-DLMH_POISON: every robot starts from an LDS image full of NaNs) is built by
+    __graft_entry__.build() and used by tests/test_gpu_round3.py to prove that no result depends on LDS nobody wrote."""
+    so = os.path.join(_HERE, "liblmh_hip_var_%s.so" % name)
+    srcs = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    if not force and os.path.exists(so) and all(os.path.getmtime(f) <= os.path.getmtime(so) for f in srcs):
+        return so
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+           "-mllvm", "-disable-machine-licm", *flags, *[os.path.join(CSRC, f) for f in SOURCES], "-o", so]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return so
+
+
 SHIM_DIR = os.path.join(CSRC, "shim")
 SHIM_SO = os.path.join(_HERE, "liblmh_shim.so")
 ROOT = os.path.dirname(_HERE)

@@ -191,6 +191,13 @@ enum {
     LDS_DOUBLES = S0 + 2512
 };
 
+// -DLMH_POISON (experiment builds only): every robot starts from an LDS image full of NaNs, so that a read of a slot nobody wrote shows up
+// as LMH_FLAG_NONFINITE deterministically instead of depending on what the previous kernel left behind
+#ifdef LMH_POISON
+#define LMH_POISON_LDS(L, n) do { for (int e_ = (int)threadIdx.x; e_ < (n); e_ += (int)blockDim.x) (L)[e_] = __longlong_as_double(0x7ff8000000000000ll); __syncthreads(); } while (0)
+#else
+#define LMH_POISON_LDS(L, n) do { } while (0)
+#endif
 // The lane id goes through an opaque (volatile) asm so that, in the rollout kernel, the large amount of
 // lane-derived index arithmetic is NOT hoisted out of the tick/stage loops: hoisting it costs 256 VGPR +
 // 256 AGPR + scratch spills (~100 MB of scratch traffic per launch) for no gain.
@@ -673,18 +680,22 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
     // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos
     // lane = (slot fr < 5, entry el < 12): five of the 28 local transforms per round, six rounds
     const int lfr = (lane < 60) ? lane / 12 : 0, lel = lane % 12;
-    R c0[6], c1[6], c2[6];
+    // an entry takes at most one trigonometric term, and which one depends on its position in the 3 x 4 only (Khalil DH: columns 0, 1
+    // of every row; cos in (0,0), (1,1), (2,1), sin in (0,1), (1,0), (2,0)): two coefficients per entry are loaded, not three
+    const bool cosT = (lel == 0) || (lel == 5) || (lel == 9);
+    const int ksel = cosT ? 1 : 2;
+    R c0[6], ck[6];
 #pragma unroll
     for (int u = 0; u < 6; u++) {
         const int sl = 5 * u + lfr;
         const LV<R> cf = lcoef + 3 * (12 * ((sl < 28) ? sl : 0) + lel);
-        c0[u] = cf[0]; c1[u] = cf[1]; c2[u] = cf[2];
+        c0[u] = cf[0]; ck[u] = cf[ksel];
     }
-    if (lane < 28) {
+    if (lane < 28) {                                               // one sincos for the 24 joint angles and roll / pitch / yaw
+        const R x = (lane < 24) ? (R)L[P_Q + 6 + lane] + (R)L[P_TAB + lane] : (R)L[P_Q + 3 + ((lane >= 25) ? lane - 25 : 0)];
         R s, c;
-        if (lane < 24) sincos_r((R)L[P_Q + 6 + lane] + (R)L[P_TAB + lane], &s, &c);
-        else if (lane == 24) { s = -1.0; c = CPI2; }              // theta[24] = -pi/2 (Robot.cpp:87)
-        else sincos_r((R)L[P_Q + 3 + (lane - 25)], &s, &c);            // roll, pitch, yaw
+        sincos_r(x, &s, &c);
+        if (lane == 24) { s = -1.0; c = CPI2; }                    // theta[24] = -pi/2 (Robot.cpp:87)
         L[P_SC + 2 * lane] = s;
         L[P_SC + 2 * lane + 1] = c;
     }
@@ -699,7 +710,7 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
         for (int u = 0; u < 6; u++) {
             const int sl = 5 * u + lfr;
             const int ss = (sl < 25) ? sl : 24;                    // slots 25..27 are constants (c1 = c2 = 0)
-            const R val = fma(c2[u], (R)L[P_SC + 2 * ss], fma(c1[u], (R)L[P_SC + 2 * ss + 1], c0[u]));
+            const R val = fma(ck[u], (R)L[P_SC + 2 * ss + (cosT ? 1 : 0)], c0[u]);
             if (lane < 60 && sl < 28) L[A_LC + 12 * sl + lel] = val;
         }
     }
@@ -1226,6 +1237,8 @@ __device__ __forceinline__ void phase_crba_mfma(double *L, const IbSel &g)
     const bool leg = b < 2;
     const int fbB = (b == 0) ? 1 : (b == 1) ? 8 : (b == 2) ? 15 : 20, fbA = (b == 2) ? 20 : fbB;
     const int jst = (b == 0) ? 0 : (b == 1) ? 6 : (b == 2) ? 12 : 17;
+    // (the matrix-core tiles of the QP set-up read two entries past row 5 of P_MTOP, i.e. P_HL[0..1], against zero padding: H has to be
+    // finite in EVERY evaluation, also in the ones whose torques nobody asks for -- found with the -DLMH_POISON build)
     for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;        // entries outside a limb's block stay zero
     // X tiles: element (4 tk + rho, 4 tj + q) of the frame's image; outside the 6 x 6 -> a stored zero of the image (row 0, column 3)
     int xo[4];
@@ -2196,7 +2209,7 @@ __device__ __forceinline__ int cone_pushthrough_f32(double *L, const LmhDevParam
 // One loop, one call site of the (large, fully unrolled) free-set solve.
 // P.bpp_max (lmh_config.bpp_rounds): 10 by default; < 0 skips block pivoting altogether (diagnostic: Lawson-Hanson from the empty set)
 template <bool F32 = false>
-__device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters, double *dbgp = nullptr)
+__device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters, int *w_done, double *dbgp = nullptr)
 {
     constexpr double TOLC = F32 ? 1e-5 : 1e-10;                   // primal sign test, relative to max |c| (fp32: ~100 ulp of the push-through solve)
     const int lane = LANE;
@@ -2204,11 +2217,7 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
     forced = (unsigned)__builtin_amdgcn_readfirstlane((int)forced);
     unsigned F = (unsigned)__builtin_amdgcn_readfirstlane((int)(*F_io & ~forced));    // scalar from here on (ballots keep it so)
     WSTAMP(30);
-    double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
-    qmax = wave_max(qmax);
-    WSTAMP(31);
-    const double toll = 1e-14 * (1.0 + qmax);                    // ~10x the round-off of (P c - q): a looser bound lets a warm start keep a coefficient
-                                                                   // out whose multiplier is slightly negative (1e-6 relative error in tau after a contact switch)
+    *w_done = 0;
     const bool mine = (lane < 32) && !((forced >> lane) & 1u);
     int ninf = 33, budget = 3;
     const int bpp_max = P.bpp_max;
@@ -2247,7 +2256,7 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
         if (gj_solve_regs<12, 1>(a, b, 0xFFFu)) flags |= LMH_FLAG_NOT_SPD;
         WSTAMP(33);
         WSYNC();
-        if (lane < 12) L[P_U12 + lane] = b[0];
+        if (lane < 12) { L[P_U12 + lane] = b[0]; L[P_W12 + lane] = b[0]; }     // the wrench itself: G c = G G'(G G')^-1 u = u
         WSYNC();
         if (lane < 32) {
             const double *gp = L + P_GPI + 6 * (lane & 15), *u = L + P_U12 + 6 * (lane >> 4);
@@ -2265,11 +2274,18 @@ __device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigne
             if (lane < 32) L[P_CC + lane] = cj;
             WSYNC();
             *F_io = F; *iters = it;
+            if constexpr (!F32) *w_done = 1;                       // P_W12 holds the wrench (the fp32 form leaves it to the recovery)
             return flags;
         }
         ninf = __popc(bad);
         F ^= bad;
     }
+    // the dual sign tests of the iteration below scale with max |q| (the all-free path above has no dual side)
+    double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
+    qmax = wave_max(qmax);
+    WSTAMP(31);
+    const double toll = 1e-14 * (1.0 + qmax);                    // ~10x the round-off of (P c - q): a looser bound lets a warm start keep a coefficient
+                                                                   // out whose multiplier is slightly negative (1e-6 relative error in tau after a contact switch)
     for (;;) {
         if (it >= P.max_qp_iters) { flags |= LMH_FLAG_QP_MAXITER; break; }    // no further solve is started once the cap is reached
         it++;
@@ -2828,9 +2844,9 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
     if (ph == LMH_PHASE_LEFT || ph == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;    // right foot carries no force
     if (ph == LMH_PHASE_RIGHT || ph == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
     unsigned F = (P.warm_start ? *Fmask_io : 0xFFFFFFFFu) & ~forced;
-    int it = 0;
+    int it = 0, w_done = 0;
     WSTAMP(24);
-    flags |= cone_qp<F32>(L, P, forced, &F, &it, dbgp);
+    flags |= cone_qp<F32>(L, P, forced, &F, &it, &w_done, dbgp);
     WSYNC();
     WSTAMP(25);
     *Fmask_io = F;
@@ -2866,17 +2882,20 @@ __device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph
         bsync<NW>();
         return flags;
     }
-    // ---- recover w = G c, lam = -Si (Jb' w - d), a = -(Y_g + Y_M lam)
-    if (lane < 12) {
-        const int ft = lane / 6, k = lane % 6;
-        double s = 0.0;
-        for (int j = 0; j < 16; j++) s += L[P_GCOL + 6 * j + k] * L[P_CC + 16 * ft + j];
-        L[P_W12 + lane] = s;
+    // ---- recover w = G c (unless the solve left the wrench behind), lam = -Si (Jb' w - d), a = -(Y_g + Y_M lam)
+    if (!w_done) {                                                 // wave-uniform
+        if (lane < 12) {
+            const int ft = lane / 6, k = lane % 6;
+            double s = 0.0;
+            for (int j = 0; j < 16; j++) s += L[P_GCOL + 6 * j + k] * L[P_CC + 16 * ft + j];
+            L[P_W12 + lane] = s;
+        }
+        WSYNC();
     }
-    WSYNC();
-    if (lane < 6) {
+    if (lane < 6) {                                                // base columns of the feet Jacobian: P_JC[foot][row][0..5]
         double s = 0.0;
-        for (int row = 0; row < 12; row++) s += jdense(L, row, lane) * L[P_W12 + row];
+#pragma unroll
+        for (int row = 0; row < 12; row++) s += L[P_JC + 72 * (row / 6) + 12 * (row % 6) + lane] * L[P_W12 + row];
         L[P_LAM6 + lane] = s - L[P_D6 + lane];                     // r = Jb' w - d (temporarily)
     }
     WSYNC();
@@ -3254,6 +3273,7 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, doubl
     const double t = st[90];
     unsigned F = 0xFFFFFFFFu;
     SET_GDBG(DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+    LMH_POISON_LDS(L, LDS_DOUBLES);
     if (wid == 0) {
         load_common(L, P, inst);
         for (int e = LANE; e < 91; e += 64) L[P_Q + e] = st[e];    // q | v | v_prev | t
@@ -3317,6 +3337,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     SET_GDBG(nullptr);
     double x = 0.0, t = st[90];
     unsigned F = 0xFFFFFFFFu;
+    LMH_POISON_LDS(L, LDS_DOUBLES);
     if (wid == 0) {
         load_common(L, P, inst);
         // lane i < 60 owns state component i (q | v); v_prev lives in LDS between evaluations

@@ -258,7 +258,7 @@ def test_config4_one_gpu_share_randomised_ik_walking():
     out, status, log = ctl.rollout(st, nt, log=True)
     torch.cuda.synchronize()
     stn, log, status = st.cpu().numpy(), log.cpu().numpy(), status.cpu().numpy()
-    assert (status[:, 2] == 0).all()
+    assert (status[:, 2] == 0).all(), (np.unique(status[:, 2]), np.nonzero(status[:, 2])[0][:8], status[status[:, 2] != 0][:4])
     t, seen = 0.0, set()
     for tk in range(nt):
         k = int((t + args.dt) / args.dt)

@@ -426,3 +426,56 @@ def test_config4_decoupled_randomised_walkers(nao):
         assert list(r["k"]) == kref and close(stn[i, :60], r["state"], 1e-6)
         for tk in list(range(0, nt, 20)) + [nt - 1]:
             assert close(log[tk, j, :24], r["log"][tk][:24]) and close(log[tk, j, 24:], r["log"][tk][24:], scale=WEIGHT), (i, tk)
+
+
+# ------------------------------------------------------------------------------- no result depends on LDS nobody wrote
+_POISON_PROBE = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+from linearmpchumanoid_amd.controller import BatchedController, default_config
+from helpers import perturbed_velocities
+ik = json.load(open("tests/golden/ik_posture.json"))
+h = hashlib.sha256()
+flags = 0
+# walking (contact switching, several robots per resident workgroup is not needed: every robot is poisoned at its start), stance, jump
+for kind in ("walk", "stance", "jump"):
+    B = 96
+    ctl = BatchedController(B, default_config(dt=1e-3, time_horizon=0.32 + 1e-9, z_com=ik["z_com"], mpc_dt=1e-2, warm_start=1))
+    if kind == "walk":
+        ctl.gen_walk(2.0, num_steps=3, time_per_step=0.3, ds_time=0.1, step_height=0.02, settle_time=0.05)
+        ctl.set_xscale(np.linspace(0.02, 0.05, B))
+    elif kind == "jump":
+        ctl.gen_jump(2.0, 0.1, 0.1)
+    else:
+        ctl.set_refs_stance(2.0, 2)
+    st = ctl.new_state(np.array(ik["q"]), perturbed_velocities(B) * 0.3, t=0.0)
+    out, status, log = ctl.rollout(st, 420, log=True)
+    o2, s2 = ctl.stand_step(st.clone())
+    torch.cuda.synchronize()
+    for a in (out, status, log, st, o2, s2):
+        h.update(a.cpu().numpy().tobytes())
+    flags += int((status.cpu().numpy()[:, 2] != 0).sum())
+print(json.dumps({"sha": h.hexdigest(), "flags": flags}))
+"""
+
+
+def test_results_do_not_depend_on_uninitialised_lds():
+    """The checker build liblmh_hip_var_poison.so (-DLMH_POISON, built by __graft_entry__.build()) fills the whole LDS image of every
+    robot with NaNs before anything is loaded.  Walking, stance and jump rollouts (all three support phases, flight, 420 ticks, log,
+    a single evaluation on top) must come out flag-free and BIT-IDENTICAL to the shipped library: no slot is read before it is written.
+    (Round 3 found one that way: two entries of the joint-space inertia that the matrix-core tiles of the QP set-up over-read against
+    zero padding.)"""
+    from linearmpchumanoid_amd import build as hipbuild
+    so = hipbuild.build_variant("poison", ["-DLMH_POISON"])
+    assert os.path.exists(so)
+    res = {}
+    for variant in ("", "poison"):
+        env = {k: v for k, v in os.environ.items() if k not in ("LMH_VARIANT", "LMH_DIAG")}
+        if variant:
+            env["LMH_VARIANT"] = variant
+        r = subprocess.run([sys.executable, "-c", _POISON_PROBE], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[variant] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res[""]["flags"] == 0 and res["poison"]["flags"] == 0, res
+    assert res[""]["sha"] == res["poison"]["sha"], res
