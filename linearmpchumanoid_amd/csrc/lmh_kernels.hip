@@ -31,6 +31,13 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "lmh_device.h"
+
+// The parameter block is read through the CONSTANT address space: a wave-uniform load from it is a scalar-cache s_load into SGPRs
+// (a generic pointer makes every field read a vector flat_load followed by a full s_waitcnt).  The block is written by the host
+// before the launch and never by a kernel, which is what that address space promises.
+typedef const __attribute__((address_space(4))) LmhDevParams LmhCParams;
+// by-value kernel argument at offset 0 of the kernarg segment, seen through the constant address space
+#define LMH_KERNARG_PARAMS() (*(LmhCParams *)__builtin_amdgcn_kernarg_segment_ptr())
 #include "../../include/lmh.h"
 
 // Wave-level fence: orders this wave's LDS traffic for the compiler; the LDS unit executes one wave's
@@ -1431,7 +1438,7 @@ __device__ __forceinline__ double jdense(const double *L, int row, int col)
 #define P_RPH (P_TIME + 2)         // support phase of sample k
 #define P_RXS (P_TIME + 3)         // the robot's step-length scale (lmh_set_xscale), 1 without
 #define P_RT0 (P_POLY + 54)        // start time of the cached swing segment (0 without segments)
-__device__ __forceinline__ void refs_prepare(double *L, const LmhDevParams &P, int inst, double t)
+__device__ __forceinline__ void refs_prepare(double *L, LmhCParams &P, int inst, double t)
 {
     const int lane = LANE;
     const int N = P.horizon;
@@ -1535,7 +1542,7 @@ __device__ __forceinline__ void refs_momentum(double *L, double mass, bool ang)
         if (lane < 3) L[P_ANGM + lane] = ang ? s : 0.0; else L[P_COMV + lane - 3] = s / mass;
     }
 }
-__device__ __forceinline__ void refs_vfoot_pdjoints(double *L, const LmhDevParams &P)
+__device__ __forceinline__ void refs_vfoot_pdjoints(double *L, LmhCParams &P)
 {
     const int lane = LANE;
     if (lane >= 8 && lane < 20) {                                  // foot velocities J vhat
@@ -1552,7 +1559,7 @@ __device__ __forceinline__ void refs_vfoot_pdjoints(double *L, const LmhDevParam
         L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
     }
 }
-__device__ __forceinline__ int refs_mpc(double *L, const LmhDevParams &P, int inst, int k, double *zcom_out)
+__device__ __forceinline__ int refs_mpc(double *L, LmhCParams &P, int inst, int k, double *zcom_out)
 {
     const int lane = LANE;
     int flags = 0;
@@ -1582,7 +1589,7 @@ __device__ __forceinline__ int refs_mpc(double *L, const LmhDevParams &P, int in
     *zcom_out = zcom;
     return flags;
 }
-__device__ __forceinline__ void refs_pd_momentum(double *L, const LmhDevParams &P, double mass, double zcom)
+__device__ __forceinline__ void refs_pd_momentum(double *L, LmhCParams &P, double mass, double zcom)
 {
     const int lane = LANE;
     if (lane < 3) {                                                // PDMomentumAcc, controller.cpp:310-325
@@ -1593,7 +1600,7 @@ __device__ __forceinline__ void refs_pd_momentum(double *L, const LmhDevParams &
         L[P_HREF + lane] = P.kd_mom * (0.0 - L[P_ANGM + lane]);
     }
 }
-__device__ __forceinline__ void refs_pd_feet(double *L, const LmhDevParams &P, int inst, double t, int k)
+__device__ __forceinline__ void refs_pd_feet(double *L, LmhCParams &P, int inst, double t, int k)
 {
     const int lane = LANE;
     if (lane >= 8 && lane < 10) {                                  // orientation error, controller.cpp:344-353
@@ -1627,7 +1634,7 @@ __device__ __forceinline__ void refs_pd_feet(double *L, const LmhDevParams &P, i
 }
 
 template <int NW>
-__device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int inst, double t, int wid, int *k_out, int *phase_out, bool ang)
+__device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, double t, int wid, int *k_out, int *phase_out, bool ang)
 {
     int flags = 0;
     const double mass = L[P_MODEL + 392];
@@ -1671,7 +1678,7 @@ __device__ __forceinline__ int phase_refs(double *L, const LmhDevParams &P, int 
 
 // Cone Hessian for the general free-set solve: WG = W G (12 x 32), P = G' WG + eps I (32 x 32), six MFMA tiles.
 // Formed lazily (cone_qp): the push-through route never reads it.
-__device__ __forceinline__ void build_cone_matrix(double *L, const LmhDevParams &P)
+__device__ __forceinline__ void build_cone_matrix(double *L, LmhCParams &P)
 {
     const int lane = LANE, tr = lane & 15, tq = lane >> 4;
     WSYNC();
@@ -1922,7 +1929,7 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
 }
 
 // `have_ki`: 1 = K_f^-1 of this F already sits in L[P_KI] (helper wave), 2 = known singular, 0 = compute here.
-__device__ __forceinline__ int cone_pushthrough(double *L, const LmhDevParams &P, unsigned F, int have_ki, double *s_out, int *flags)
+__device__ __forceinline__ int cone_pushthrough(double *L, LmhCParams &P, unsigned F, int have_ki, double *s_out, int *flags)
 {
     const int lane = LANE;
     const unsigned FR = F & 0xFFFFu, FL = F >> 16;
@@ -2021,7 +2028,7 @@ __device__ __forceinline__ int gj_lds_f32(double *A, int n, int m, int ld, unsig
 }
 
 // controller.cpp:94-132 + the equality blocks of :388-436 down to W, h, qv, in fp32.  nU = 15 or 18 rows of U = [AG ; J] (run time).
-__device__ __forceinline__ int qp_setup_f32(double *L, const LmhDevParams &P)
+__device__ __forceinline__ int qp_setup_f32(double *L, LmhCParams &P)
 {
     const int lane = LANE;
     int flags = 0;
@@ -2152,7 +2159,7 @@ __device__ __forceinline__ int pushthrough_solve_f32(double *L, const double *Ki
 // fp32 form of cone_pushthrough: K_f = G_F G_F' and its inverse by Gauss-Jordan in fp32 (a pivot below 1e-4 of its diagonal = rank
 // deficient: return 0, the caller takes the fp64 general route), the 12 x 12 solve above, y = K^-1 w, s_j = g_j' y.
 // `fmask_out`: bit f set = foot f carries free coefficients (its multipliers are -eps s_j, accurate to eps * 1e-6 |s|).
-__device__ __forceinline__ int cone_pushthrough_f32(double *L, const LmhDevParams &P, unsigned F, double *s_out, int *flags)
+__device__ __forceinline__ int cone_pushthrough_f32(double *L, LmhCParams &P, unsigned F, double *s_out, int *flags)
 {
     const int lane = LANE;
     const unsigned FR = F & 0xFFFFu, FL = F >> 16;
@@ -2209,7 +2216,7 @@ __device__ __forceinline__ int cone_pushthrough_f32(double *L, const LmhDevParam
 // One loop, one call site of the (large, fully unrolled) free-set solve.
 // P.bpp_max (lmh_config.bpp_rounds): 10 by default; < 0 skips block pivoting altogether (diagnostic: Lawson-Hanson from the empty set)
 template <bool F32 = false>
-__device__ __forceinline__ int cone_qp(double *L, const LmhDevParams &P, unsigned forced, unsigned *F_io, int *iters, int *w_done, double *dbgp = nullptr)
+__device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced, unsigned *F_io, int *iters, int *w_done, double *dbgp = nullptr)
 {
     constexpr double TOLC = F32 ? 1e-5 : 1e-10;                   // primal sign test, relative to max |c| (fp32: ~100 ulp of the push-through solve)
     const int lane = LANE;
@@ -2385,7 +2392,7 @@ __device__ __forceinline__ v4d mfma_ptr(const double *a0, const double *b0)
 // The Jacobian rows of U and U D^-1 (rows 0..11 of the padded operands).  They depend on wave 0's own products only and land in LDS that is
 // dead once its Newton-Euler pass is over (S0 + [0, 408) and S0 + [544, 952): the NE sweeps' scratch and the FK transforms), so on the
 // two-wave schedule wave 0 writes them while wave 1 is still inside CRBA / its reference chain, ahead of the join.
-__device__ __forceinline__ void qp_prefill15(double *L, const LmhDevParams &P)
+__device__ __forceinline__ void qp_prefill15(double *L, LmhCParams &P)
 {
     const int lane = LANE;
     const double idp = P.inv_w_base_pos, ida = P.inv_w_base_ang, idj = P.inv_w_joints;
@@ -2410,7 +2417,7 @@ __device__ __forceinline__ void qp_prefill15(double *L, const LmhDevParams &P)
 //     wave while wave 0 solves; the Y tiles (needed only by the recovery) are formed by the helper wave while wave 0 goes on to S^-1, W, h.
 // NW = 2 joins: fills | Cm, q+V | solve, Z+Mbp | (S..qv), Y | -> the caller's join in front of the cone solve.
 template <int NW>
-__device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int wid, double *dbgp)
+__device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, double *dbgp)
 {
     const int lane = LANE;
     int flags = 0;
@@ -2618,7 +2625,7 @@ __device__ __forceinline__ int qp_setup15(double *L, const LmhDevParams &P, int 
 // QP set-up (controller.cpp:94-132 Hessian/gradient and the equality blocks of :388-436) down to the cone
 // problem data P, qv; NU = rows of U = [AG ; J] that carry weight (15 when the angular-momentum weight is 0).
 template <int NU, int NW>
-__device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wid, double *dbgp)
+__device__ __forceinline__ int qp_setup(double *L, LmhCParams &P, int wid, double *dbgp)
 {
     const int lane = LANE;
     int flags = 0;
@@ -2823,7 +2830,7 @@ __device__ __forceinline__ int qp_setup(double *L, const LmhDevParams &P, int wi
 
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
 template <int NW, bool F32 = false>
-__device__ __forceinline__ int phase_qp(double *L, const LmhDevParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
+__device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
 {
     const int lane = LANE;
     int flags;
@@ -2933,7 +2940,7 @@ enum { PL_VF = S0 + 0,      // 8 x 6 : r_v x f_v | f_v per vertex
        PL_DAB = S0 + 300,   // 6
        PL_AP = S0 + 306,    // 30 : plant acceleration (WBC coordinates)
        PL_ZERO = S0 + 336 }; // 32
-__device__ __forceinline__ void phase_plant(double *L, const LmhDevParams &P)
+__device__ __forceinline__ void phase_plant(double *L, LmhCParams &P)
 {
     const int lane = LANE;
     if (lane < 8) {                                                // one lane per (foot, vertex)
@@ -3087,7 +3094,7 @@ __device__ __forceinline__ void phase_outputs_qdd(double *L, int a_src = P_A)
 // are wave-local.  Wave 1 never touches P_Q / P_V / the QP scratch after its last bsync, so wave 0 may run ahead
 // into the next evaluation's forward kinematics.
 template <int NW, typename R, bool QF32 = false>
-__device__ __forceinline__ int controller_eval(double *L, const LmhDevParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg, bool need_tau = true)
+__device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg, bool need_tau = true)
 {
     int flags = 0, ph = 0;
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
@@ -3207,7 +3214,7 @@ __device__ __forceinline__ void load_tables(double *L)
 {
     if (LANE < 24) L[P_TAB + LANE] = c_dh_off[LANE];               // theta offsets, Robot.cpp:59-87
 }
-__device__ __forceinline__ void load_common(double *L, const LmhDevParams &P, int inst)
+__device__ __forceinline__ void load_common(double *L, LmhCParams &P, int inst)
 {
     const double *mo = P.model + (size_t)P.model_stride * inst;
     for (int e = LANE; e < 393; e += 64) L[P_MODEL + e] = mo[e];
@@ -3263,8 +3270,9 @@ __device__ __forceinline__ void store_out(const double *L, double *out)
 // The plain kernel runs two waves per robot like the rollout; the debug kernel (intermediate dumps, stamps) keeps
 // the single-wave schedule.
 template <bool DEBUG, typename R, int NW = (DEBUG ? 1 : 2), bool QF32 = false>
-__global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P, double *state, double *out, int32_t *status, double *debug)
+__global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, double *state, double *out, int32_t *status, double *debug)
 {
+    LmhCParams &P = LMH_KERNARG_PARAMS();
     __shared__ double L[LDS_DOUBLES];
     const int inst = blockIdx.x;
     if (inst >= P.n_instances) return;
@@ -3319,7 +3327,8 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     // of the tick loop pins them in SGPRs for the whole launch (round 1: 189 SGPR + 16 VGPR spills, 60 B of scratch per lane that reached
     // HBM); re-reading them costs a few scalar-cache loads per evaluation.
     __shared__ double L[LDS_DOUBLES];
-    const LmhDevParams &P = *Pg;
+    LmhCParams *Pc = (LmhCParams *)(uintptr_t)Pg;
+    LmhCParams &P = *Pc;
     // One workgroup runs several robots one after the other (grid = the number of workgroups the chip holds at once, lmh_launch_rollout):
     // when the hardware dispatcher refills the chip from a longer grid, throughput drops by ~15 % (measured: 1024 robots 4.1 ms per launch,
     // 2048 robots 11.4 ms, 4096 robots 19.2 ms for the same 40 ticks); looping inside the resident workgroups keeps the first round's placement.
@@ -3366,7 +3375,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
                 if (lane < 60) L[P_Q + lane] = xs;
                 WSYNC();
             }
-            const LmhDevParams *Pe = Pg;
+            LmhCParams *Pe = Pc;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
             flags |= controller_eval<2, R, QF32>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3);
             if (wid == 0) {
@@ -3511,8 +3520,9 @@ __device__ void inv3_dev(const double *A, double *Ai)
     Ai[6] = (A[3] * A[7] - A[4] * A[6]) / det; Ai[7] = (A[1] * A[6] - A[0] * A[7]) / det; Ai[8] = (A[0] * A[4] - A[1] * A[3]) / det;
 }
 
-__global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P, double *qio, LmhIkTarget tgt, int32_t *iters_out)
+__global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P_arg, double *qio, LmhIkTarget tgt, int32_t *iters_out)
 {
+    LmhCParams &P = LMH_KERNARG_PARAMS();
     __shared__ double L[IK_LDS];
     const int inst = blockIdx.x;
     if (inst >= P.n_instances) return;
@@ -3699,8 +3709,9 @@ extern "C" void lmh_launch_summary(int n, const double *state, const double *out
 }
 
 // Robot::updateState + getCoM (Robot.cpp:264-269,225-238) for q only.
-__global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P, const double *q, double *com)
+__global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P_arg, const double *q, double *com)
 {
+    LmhCParams &P = LMH_KERNARG_PARAMS();
     __shared__ double L[LDS_DOUBLES];
     const int inst = blockIdx.x;
     if (inst >= P.n_instances) return;
