@@ -144,10 +144,13 @@ enum {
     P_END = 2602,
     // ---- scratch, tree phases (kinematics, Newton-Euler, CRBA, Jacobian)
     S0 = P_END,
-    A_LC = S0 + 0,    // 28 x 12 local transforms (dead after FK)
+    A_LC = S0 + 0,    // 28 x 12 local transforms (dead once the chain products have loaded them: A_T takes their place)
+    A_T = S0 + 0,     // 30 x 12 world transforms (dead after phase_com_x; the IK kernel reads them later).  S0 + [0, 384) is the one piece of
+                      // scratch the cone solve of the shipped kernels never touches (C_WG is formed for the debug dump only), which is what lets
+                      // the helper wave run the NEXT evaluation's kinematics there while wave 0 is still solving (lmh_rollout_kernel)
+    A_T0S = S0 + 360, // 12 + 6: T0 and the sin / cos of roll, pitch, yaw while the chains start (look-ahead kinematics)
     A_VEL = S0 + 0, A_ACCG = S0 + 168, A_ACC0 = S0 + 336, A_FG = S0 + 504, A_F0 = S0 + 672,     // Newton-Euler: 28 x 6 each (wave 0)
-    A_JL = S0 + 0,    // 2 x 6 x 12 feet Jacobian in sole axes (wave 0, after its Newton-Euler pass)
-    A_T = S0 + 840,   // 30 x 12 world transforms (dead after phase_com_x; the IK kernel reads them later)
+    A_JL = S0 + 384,  // 2 x 6 x 12 feet Jacobian in sole axes (wave 0, after its Newton-Euler pass; clear of A_T, which the IK kernel reads after it)
     A_XF = S0 + 1200, // 28 x 36 : X_i = [A 0; B A] as full 6 x 6 images (row r contiguous, column r at stride 6)
     A_XP = S0 + 2208, // 28 x 3 : p_i
     A_XR = S0 + 2300, // 5 x 36 limb-root contributions to Ic_0 (CRBA, wave 1) | scratch of the helper wave's kinv_compute during the kinematics
@@ -195,7 +198,9 @@ enum {
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
     C_LS = S0 + 1440, // 32 x 33 rows of L for the backward substitution
     C_IDX = S0 + 2496, // 32 ints: compact position -> coefficient index
-    LDS_DOUBLES = S0 + 2512
+    P_SCB = S0 + 2512, // sin / cos of pitch and yaw (4), second buffer: the look-ahead kinematics of evaluation n + 1 write one buffer while the
+                       // integrator of evaluation n still reads the other (P_SC + 52 is the first)
+    LDS_DOUBLES = S0 + 2516   // 40928 B + 4 B (ticket) per robot: four robots per CU fill 163.7 of the 163.84 KB
 };
 
 // -DLMH_POISON (experiment builds only): every robot starts from an LDS image full of NaNs, so that a read of a slot nobody wrote shows up
@@ -680,10 +685,13 @@ __device__ __forceinline__ void sincos_r(float x, float *s, float *c) { sincosf(
 // ============================================================================ kinematics
 // Robot::forwardKinematics + matTrans + eulerAnglesToSO3 (Robot.cpp:45-160,176-223,
 // generalizedFunctions.cpp:52-72).  Reads L[P_Q], writes A_T (30 x 3x4) and L[P_SC].
-template <typename R>
-__device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
+// AHEAD (helper wave of the rollout, inside the previous evaluation): the configuration comes from a register (lane i < 30 holds q_i)
+// instead of L[P_Q], the roll / pitch / yaw terms go to scratch, and the four the integrator reads (sin / cos of pitch and yaw) to `xd4`.
+template <typename R, bool AHEAD = false>
+__device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0, int xd4 = P_SC + 52)
 {
     const int lane = LANE;
+    constexpr int RPY = AHEAD ? (int)A_T0S + 12 : (int)P_SC + 50;
     // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos
     // lane = (slot fr < 5, entry el < 12): five of the 28 local transforms per round, six rounds
     const int lfr = (lane < 60) ? lane / 12 : 0, lel = lane % 12;
@@ -698,13 +706,22 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
         const LV<R> cf = lcoef + 3 * (12 * ((sl < 28) ? sl : 0) + lel);
         c0[u] = cf[0]; ck[u] = cf[ksel];
     }
+    R qa = (R)0, qpos = (R)0;
+    if constexpr (AHEAD) {                                         // lane permutes, outside the branches
+        qa = __shfl(qn, (lane < 24) ? 6 + lane : (lane >= 25 && lane < 28) ? lane - 22 : 0, 64);
+        qpos = __shfl(qn, (lane < 12) ? (lane >> 2) : 0, 64);
+    }
     if (lane < 28) {                                               // one sincos for the 24 joint angles and roll / pitch / yaw
-        const R x = (lane < 24) ? (R)L[P_Q + 6 + lane] + (R)L[P_TAB + lane] : (R)L[P_Q + 3 + ((lane >= 25) ? lane - 25 : 0)];
+        R x;
+        if constexpr (AHEAD) x = (lane < 24) ? qa + (R)L[P_TAB + lane] : qa;
+        else x = (lane < 24) ? (R)L[P_Q + 6 + lane] + (R)L[P_TAB + lane] : (R)L[P_Q + 3 + ((lane >= 25) ? lane - 25 : 0)];
         R s, c;
         sincos_r(x, &s, &c);
         if (lane == 24) { s = -1.0; c = CPI2; }                    // theta[24] = -pi/2 (Robot.cpp:87)
-        L[P_SC + 2 * lane] = s;
-        L[P_SC + 2 * lane + 1] = c;
+        const int so = (lane < 25) ? P_SC + 2 * lane : RPY + 2 * (lane - 25);
+        L[so] = s;
+        L[so + 1] = c;
+        if (AHEAD && lane >= 26) { L[xd4 + 2 * (lane - 26)] = s; L[xd4 + 2 * (lane - 26) + 1] = c; }
     }
     WSYNC();
     SUBSTAMP(0);
@@ -723,23 +740,24 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
     }
     if (lane < 12) {                                               // T0 = [R(rpy) p]
         const int r = lane >> 2, col = lane & 3;
-        const R sr = L[P_SC + 50], cr = L[P_SC + 51], sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
+        const R sr = L[RPY + 0], cr = L[RPY + 1], sp = L[RPY + 2], cp = L[RPY + 3], sy = L[RPY + 4], cy = L[RPY + 5];
         R val;
-        if (col == 3) val = L[P_Q + r];
+        if (col == 3) { if constexpr (AHEAD) val = qpos; else val = L[P_Q + r]; }
         else if (r == 0) val = (col == 0) ? cy * cp : (col == 1) ? cy * sp * sr - sy * cr : cy * sp * cr + sy * sr;
         else if (r == 1) val = (col == 0) ? sy * cp : (col == 1) ? sy * sp * sr + cy * cr : sy * sp * cr - cy * sr;
         else val = (col == 0) ? -sp : (col == 1) ? cp * sr : cp * cr;
-        L[A_T + lane] = val;
+        L[A_T0S + lane] = val;
     }
     SUBSTAMP(1);
     WSTAMP(45);
     // Chain products T_dst = T_src Lc: every chain is a path (step s reads what step s - 1 wrote), and lane 12 c + 4 r + col holds entry
     // (r, col) -- the four lanes of a quad are one row of the chain's current transform.  So the recurrence stays in a register and the
     // row of T_src comes from three quad broadcasts (DPP quad_perm) instead of an LDS store / fence / load per step; the local transforms
-    // do not depend on the recurrence, their loads issue ahead of it.
+    // do not depend on the recurrence: all 24 of a lane are loaded before its first step, and from there on the world transforms are
+    // written over them (A_T and A_LC are the same 360 doubles).
     const int c = (lane < 60) ? lane / 12 : 4, el = lane % 12, col = el & 3;
     WSYNC();
-    R tcur = L[A_T + el];                                          // T0 (every chain starts from the base)
+    R tcur = L[A_T0S + el];                                        // T0 (every chain starts from the base)
     R l0[8], l1[8], l2[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) {                                  // all 24 operand loads before the first dependent step
@@ -748,6 +766,8 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef)
         const LV<R> Lo = L + A_LC + 12 * (((lane < 60) && (dst >= 0)) ? loc : 0) + col;
         l0[s] = Lo[0]; l1[s] = Lo[4]; l2[s] = Lo[8];
     }
+    WSYNC();                                                       // every lane has its local transforms: their place is free
+    if (lane < 12) L[A_T + lane] = tcur;
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         int dst, src, loc;
@@ -2828,22 +2848,50 @@ __device__ __forceinline__ int qp_setup(double *L, LmhCParams &P, int wid, doubl
     return flags;
 }
 
+// K_f^-1 of the free set the cone solve will start from (same rule as phase_qp: previous active set minus the coefficients of feet out of
+// support), prepared by the helper wave; scratch: the CRBA parking area.  Needs the support phase of THIS evaluation in L[P_RPH].
+__device__ __forceinline__ void kinv_prework(double *L, LmhCParams &P)
+{
+    const int ph0 = __builtin_amdgcn_readfirstlane((int)L[P_RPH]);
+    unsigned forced = 0u;
+    if (ph0 == LMH_PHASE_LEFT || ph0 == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;
+    if (ph0 == LMH_PHASE_RIGHT || ph0 == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
+    const unsigned Fpub = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)L[P_KF]);
+    const unsigned F0 = (P.warm_start ? Fpub : 0xFFFFFFFFu) & ~forced;
+    int st = 0;
+    if (F0 != 0xFFFFFFFFu) {                                       // all free: the constant table is used instead
+        // a foot with 1..5 free generators has K_f = sum of fewer than six rank-one terms: singular without looking (the usual case in
+        // single support, where the sole presses on an edge)
+        const int nR = __popc(F0 & 0xFFFFu), nL = __popc(F0 >> 16);
+        const bool thin = (nR > 0 && nR < 6) || (nL > 0 && nL < 6);
+        st = thin ? 2 : (kinv_compute(L, F0, L + P_KI, L + A_XR) ? 2 : 1);
+    }
+    if (LANE == 0) { L[P_KF + 1] = (double)F0; L[P_KF + 2] = (double)st; }
+}
+
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
-template <int NW, bool F32 = false>
-__device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr)
+// PIPE (rollout): the helper wave prepares K_f^-1 at the end of its set-up share instead of at the start of the evaluation, and spends the
+// cone solve -- wave 0 alone -- inside `window` (the next evaluation's clock references and kinematics, lmh_rollout_kernel).
+struct NoWindow { __device__ __forceinline__ void operator()() const {} };
+template <int NW, bool F32 = false, bool PIPE = false, class WF = NoWindow>
+__device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr, WF window = WF())
 {
     const int lane = LANE;
     int flags;
     if (NW == 2 && wid == 0) { refs_agpqp(L, L[P_MODEL + 392], (P.w_com_ang != 0.0) || (dbgp != nullptr)); WSYNC(); }     // first point where both M (wave 1) and Cg (wave 0) exist
     if constexpr (F32) {
-        if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
+        if (NW == 2 && wid != 0) { if constexpr (PIPE) window(); bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
         flags = qp_setup_f32(L, P);
     } else {
     flags = (P.w_com_ang == 0.0) ? qp_setup15<NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
+    if (PIPE && NW == 2 && wid == 1) kinv_prework(L, P);           // scratch S0 + [2300, 2480): above every array of the set-up
     WSTAMP(18);
     bsync<NW>();                                                   // Y (helper wave) is complete; the cone solve may overwrite the set-up scratch
-    if (NW == 2 && wid != 0) { WSTAMP(26); bsync<NW>(); WSTAMP(27); return 0; }            // the active-set iteration and the recovery are sequential: wave 0;
-                                                                   // the helper waits for the free set it will prepare K^-1 for
+    if (NW == 2 && wid != 0) {                                     // the active-set iteration and the recovery are sequential: wave 0
+        if constexpr (PIPE) window();
+        WSTAMP(26); bsync<NW>(); WSTAMP(27);
+        return 0;
+    }
     }
     if (dbgp && LANE == 0) dbgp[4012] = (double)clock64();
     // ---- bound-constrained QP  min 1/2 c'Pc - qv'c, c >= 0  (forced zeros for feet out of support)
@@ -2932,14 +2980,15 @@ __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wi
 // products.  M = [Ic0 F2; F2' H] with H block diagonal
 // per limb (legs 6x6, arms 5x5, head 2x2): the four limb blocks are eliminated at once on the four DPP rows (Gauss-Jordan, 7 right-hand
 // sides [r_l | F2_l']), the 6x6 base Schur complement (not symmetric: the reference's inertia typos) by one more Gauss-Jordan.
-enum { PL_VF = S0 + 0,      // 8 x 6 : r_v x f_v | f_v per vertex
-       PL_DW = S0 + 48,     // 12 : w_c - w
-       PL_R = S0 + 60,      // 30 : J'(w_c - w)
-       PL_B = S0 + 90,      // 24 x 7 : H^-1 [r_J | F2']
-       PL_SB = S0 + 258,    // 6 x 7 : Schur complement | right-hand side
-       PL_DAB = S0 + 300,   // 6
-       PL_AP = S0 + 306,    // 30 : plant acceleration (WBC coordinates)
-       PL_ZERO = S0 + 336 }; // 32
+enum { PL_0 = S0 + 384,     // above S0 + [0, 384): the next evaluation's world transforms may already be there (look-ahead kinematics)
+       PL_VF = PL_0 + 0,    // 8 x 6 : r_v x f_v | f_v per vertex
+       PL_DW = PL_0 + 48,   // 12 : w_c - w
+       PL_R = PL_0 + 60,    // 30 : J'(w_c - w)
+       PL_B = PL_0 + 90,    // 24 x 7 : H^-1 [r_J | F2']
+       PL_SB = PL_0 + 258,  // 6 x 7 : Schur complement | right-hand side
+       PL_DAB = PL_0 + 300, // 6
+       PL_AP = PL_0 + 306,  // 30 : plant acceleration (WBC coordinates)
+       PL_ZERO = PL_0 + 336 }; // 32
 __device__ __forceinline__ void phase_plant(double *L, LmhCParams &P)
 {
     const int lane = LANE;
@@ -3093,8 +3142,10 @@ __device__ __forceinline__ void phase_outputs_qdd(double *L, int a_src = P_A)
 // call this with their wave index; every bsync below is reached by both (uniform control flow), all other fences
 // are wave-local.  Wave 1 never touches P_Q / P_V / the QP scratch after its last bsync, so wave 0 may run ahead
 // into the next evaluation's forward kinematics.
-template <int NW, typename R, bool QF32 = false>
-__device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg, bool need_tau = true)
+// PIPE (rollout kernel only): the kinematics of this evaluation were run ahead by the helper wave, inside the previous evaluation's
+// `window` (phase_qp), and so were the clock-only references; wave 0 starts at the X images.
+template <int NW, typename R, bool QF32 = false, bool PIPE = false, class WF = NoWindow>
+__device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg, bool need_tau = true, WF window = WF())
 {
     int flags = 0, ph = 0;
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
@@ -3103,35 +3154,24 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     WSTAMP(0);
     IbSel ibsel;                                                   // gather tables of the matrix-core CRBA: constant-memory loads, issued long before their use
     if constexpr (std::is_same_v<R, double>) { if (NW == 1 || wid == 1) ibsel = ib_select(); }
-    if (NW == 2 && wid == 1) {
+    if (NW == 2 && wid == 1 && !PIPE) {
         // while wave 0 runs the forward kinematics: the clock-only references, then K_f^-1 of the free set the cone solve will start from
-        // (same rule as phase_qp: previous active set minus the coefficients of feet out of support); scratch: the CRBA parking area
         refs_prepare(L, P, inst, t);
         WSYNC();
-        const int ph0 = __builtin_amdgcn_readfirstlane((int)L[P_RPH]);
-        unsigned forced = 0u;
-        if (ph0 == LMH_PHASE_LEFT || ph0 == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;
-        if (ph0 == LMH_PHASE_RIGHT || ph0 == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
-        const unsigned Fpub = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)L[P_KF]);
-        const unsigned F0 = (P.warm_start ? Fpub : 0xFFFFFFFFu) & ~forced;
-        int st = 0;
-        if (F0 != 0xFFFFFFFFu) {                                   // all free: the constant table is used instead
-            // a foot with 1..5 free generators has K_f = sum of fewer than six rank-one terms: singular without looking (the usual case in
-            // single support, where the sole presses on an edge)
-            const int nR = __popc(F0 & 0xFFFFu), nL = __popc(F0 >> 16);
-            const bool thin = (nR > 0 && nR < 6) || (nL > 0 && nL < 6);
-            st = thin ? 2 : (kinv_compute(L, F0, L + P_KI, L + A_XR) ? 2 : 1);
-        }
-        if (LANE == 0) { L[P_KF + 1] = (double)F0; L[P_KF + 2] = (double)st; }
+        kinv_prework(L, P);
     }
     if constexpr (NW == 1) {                                       // single-wave schedule: no K^-1 prepared; references first
         if (LANE == 0) L[P_KF + 2] = 0.0;
         refs_prepare(L, P, inst, t);
         WSYNC();
     }
-    if (wid == 0) phase_fk<R>(L, P.gcol + 228);
+    if (wid == 0 && !PIPE) phase_fk<R>(L, P.gcol + 228);
     WSTAMP(1);
-    bsync<NW>();
+    const bool plant = P.plant != 0;                               // wave-uniform
+    // PIPE: the join that ended the previous evaluation already published the world transforms, and until the next join neither wave
+    // writes what the other reads (wave 0: qdd, the state, X images of frames 0..13, persistent copies; wave 1: torques, CoM, frames
+    // 14..27) -- except the plant, whose idle-lane stores (Q_TRASH) fall on wave 1's share of A_XP
+    if (!PIPE || plant) bsync<NW>();
     WSTAMP(2);
     STAMP(1);
     phase_com_x<NW, R>(L, wid);
@@ -3148,7 +3188,6 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
         for (int e = LANE; e < 84; e += 64) dbg[588 + e] = L[A_XP + e];
     }
     STAMP(3);
-    const bool plant = P.plant != 0;                               // wave-uniform
     if constexpr (NW == 1) {
         phase_newton_euler<R>(L);
         if (plant) phase_newton_euler<R, true>(L);                 // the plant's velocity products at the CURRENT velocity (before CRBA reuses the scratch)
@@ -3178,7 +3217,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     bsync<NW>();
     WSTAMP(8);
     STAMP(7);
-    flags |= phase_qp<NW, QF32>(L, P, ph, wid, Fmask, iters_out, dbg);
+    flags |= phase_qp<NW, QF32, PIPE, WF>(L, P, ph, wid, Fmask, iters_out, dbg, window);
     STAMP(8);
     if (plant && (NW == 1 || wid == 0)) phase_plant(L, P);         // the torques drive a plant instead of being thrown away (main.cpp:118-121)
     // need_tau (wave-uniform): the integrator never reads the torques -- the rollout asks for them at the k4 stage only (log, final record)
@@ -3305,6 +3344,37 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, d
     }
 }
 
+// One stage of rk4Step (rk4.hpp:5-18) for state component `lane` < 60 (q | v): xdot of apps/offline/main.cpp:107-121 from the evaluation that
+// has just run, then the stage bookkeeping -- ksum collects k1 + 2 k2 + 2 k3 + k4, xs is the state of the next evaluation, x the state at the
+// start of the tick (advanced by the fourth stage).  `xd4`: LDS index of sin / cos of pitch and yaw of THIS evaluation's configuration.
+// The position half (lane < 30) reads nothing the evaluation produces, which is what lets the helper wave call this ahead of wave 0
+// (its lanes >= 30 then hold don't-cares).
+__device__ __forceinline__ void rk4_stage(const double *L, int stage, int lane, double dt, int xd4, double &x, double &ksum, double &xs)
+{
+    double xd = 0.0;
+    if (lane < 60) {
+        if (lane >= 30) xd = L[P_QDD + lane - 30];
+        else if (lane >= 6) xd = L[P_V + lane];
+        else if (lane < 3) {
+            const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
+            const double p0 = L[P_Q], p1 = L[P_Q + 1], p2 = L[P_Q + 2];
+            const double cr = (lane == 0) ? (-w2 * p1 + w1 * p2) : (lane == 1) ? (w2 * p0 - w0 * p2) : (-w1 * p0 + w0 * p1);
+            xd = L[P_V + lane] + cr;                               // v_classic = v_spatial + w x p
+        } else {
+            const double sp = L[xd4], cp = L[xd4 + 1], sy = L[xd4 + 2], cy = L[xd4 + 3];
+            const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
+            const double tp = sp / cp;
+            xd = (lane == 3) ? (cy / cp) * w0 + (sy / cp) * w1 + 0.0 * w2
+               : (lane == 4) ? (-sy) * w0 + cy * w1 + 0.0 * w2
+                             : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
+        }
+    }
+    if (stage == 0) { ksum = xd; xs = x + 0.5 * dt * xd; }                              // rk4.hpp:12-17
+    else if (stage == 1) { ksum = ksum + 2.0 * xd; xs = x + 0.5 * dt * xd; }
+    else if (stage == 2) { ksum = ksum + 2.0 * xd; xs = x + dt * xd; }
+    else { ksum = ksum + xd; x = x + (dt / 6.0) * ksum; xs = x; }
+}
+
 // Closed loop of apps/offline/main.cpp:66-122: n_ticks x rk4Step(dynamics) with Clock::step.
 // Workgroup = LMH_ROLLOUT_THREADS = 2 waves per robot (see bsync): 4 robots = 8 waves per CU, two per SIMD, so the
 // kernel is held to 256 registers.  Wave 0 owns the RK4 state (lane i < 60 <-> component i) and everything
@@ -3344,19 +3414,30 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double *st = state + (size_t)LMH_STATE_STRIDE * inst;
     SET_GDBG(nullptr);
+    // lane i < 60 of wave 0 owns state component i (q | v); v_prev lives in LDS between evaluations.  Wave 1 integrates its own copy of the
+    // position half (lane i < 30): the position part of xdot depends on the stage's state only, not on the evaluation's result, so the
+    // helper wave knows the NEXT evaluation's configuration while wave 0 is still solving this one's QP -- and runs that evaluation's
+    // forward kinematics there (window below).
+    // Not with the fp32 QP (tolerance sweep): its set-up runs on wave 0 alone and uses all of the scratch; that build keeps the plain schedule.
+    constexpr bool PIPE = !QF32;
     double x = 0.0, t = st[90];
     unsigned F = 0xFFFFFFFFu;
     LMH_POISON_LDS(L, LDS_DOUBLES);
     if (wid == 0) {
         load_common(L, P, inst);
-        // lane i < 60 owns state component i (q | v); v_prev lives in LDS between evaluations
         x = (lane < 60) ? st[lane] : 0.0;
         if (lane < 30) L[P_VP + lane] = st[60 + lane];
         F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
         F = P.warm_start ? ~F : 0xFFFFFFFFu;
         if (lane == 0) L[P_KF] = (double)F;
-    }
+        if constexpr (PIPE) {
+            if (lane < 60) L[P_Q + lane] = x;
+            WSYNC();
+            phase_fk<R>(L, P.gcol + 228);                          // kinematics of the first evaluation (every later one is run ahead by wave 1)
+        }
+    } else x = (lane < 30) ? st[lane] : 0.0;
     bsync<2>();
+    if (PIPE && wid == 1) refs_prepare(L, P, inst, t);             // clock-only references of the first evaluation (needs load_common's cache reset)
     int k = 0, iters = 0, flags = 0, itmax = 0;
     const double dt = P.dt;
 #ifdef LMH_SUBSTAMPS
@@ -3370,6 +3451,10 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
         double ksum = 0.0, xs = x;
         for (int stage = 0; stage < 4; stage++) {
             const double ts = (stage == 0) ? t : (stage == 3) ? t + dt : t + 0.5 * dt;      // rk4.hpp:12-15
+            const double tn = (stage < 2) ? t + 0.5 * dt : t + dt;                          // time of the evaluation after this one (the next tick starts at t + dt)
+            // sin / cos of pitch, yaw of this evaluation | of the next: the other buffer
+            const int xd4 = (PIPE && (stage & 1)) ? (int)P_SCB : (int)P_SC + 52;
+            const int xd4n = (stage & 1) ? (int)P_SC + 52 : (int)P_SCB;
             if (wid == 0) {
                 WSYNC();
                 if (lane < 60) L[P_Q + lane] = xs;
@@ -3377,38 +3462,24 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             }
             LmhCParams *Pe = Pc;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
-            flags |= controller_eval<2, R, QF32>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3);
+            // wave 1, while wave 0 runs the cone solve and the recovery: the next stage's configuration (rk4_stage, position half), the
+            // clock-only references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick) and its forward
+            // kinematics.  The world transforms land in S0 + [0, 378), which nothing touches until the next evaluation's phase_com_x.
+            auto window = [&]() {
+                rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);
+                if (tn != ts) refs_prepare(L, *Pe, inst, tn);
+                phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
+            };
+            flags |= controller_eval<2, R, QF32, PIPE, decltype(window)>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3, window);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
-                // xdot (apps/offline/main.cpp:107-121)
-                double xd = 0.0;
-                if (lane < 60) {
-                    if (lane >= 30) xd = L[P_QDD + lane - 30];
-                    else if (lane >= 6) xd = L[P_V + lane];
-                    else if (lane < 3) {
-                        const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
-                        const double p0 = L[P_Q], p1 = L[P_Q + 1], p2 = L[P_Q + 2];
-                        const double cr = (lane == 0) ? (-w2 * p1 + w1 * p2) : (lane == 1) ? (w2 * p0 - w0 * p2) : (-w1 * p0 + w0 * p1);
-                        xd = L[P_V + lane] + cr;                   // v_classic = v_spatial + w x p
-                    } else {
-                        const double sp = L[P_SC + 52], cp = L[P_SC + 53], sy = L[P_SC + 54], cy = L[P_SC + 55];
-                        const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
-                        const double tp = sp / cp;
-                        xd = (lane == 3) ? (cy / cp) * w0 + (sy / cp) * w1 + 0.0 * w2
-                           : (lane == 4) ? (-sy) * w0 + cy * w1 + 0.0 * w2
-                                         : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
-                    }
-                }
+                const double xprev = xs;
+                rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);
                 // Robot::v_ <- dq for the next evaluation
                 WSYNC();
-                if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xs;
-                if (stage == 0) { ksum = xd; xs = x + 0.5 * dt * xd; }
-                else if (stage == 1) { ksum = ksum + 2.0 * xd; xs = x + 0.5 * dt * xd; }
-                else if (stage == 2) { ksum = ksum + 2.0 * xd; xs = x + dt * xd; }
-                else { ksum = ksum + xd; }
+                if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xprev;
             }
         }
-        if (wid == 0) x = x + (dt / 6.0) * ksum;                    // rk4.hpp:17
         if (log) {                                                  // each wave logs what it produced: wave 1 the torques, wave 0 the wrench
             double *lg = log + ((size_t)tick * P.n_instances + inst) * 36;
             if (wid != 0) { if (lane < 24) lg[lane] = L[P_TAU + lane]; }

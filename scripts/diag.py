@@ -8,8 +8,8 @@
       share of the PRODUCTION rollout kernel's cycles that each wave of a robot spends inside workgroup barriers.
   python scripts/diag.py rounds [config=3] [ticks=4000] [chunk=100]
       QP round histogram (status[:, 1] = max rounds per launch) and flag counts along a rollout of bench.py's workload.
-  python scripts/diag.py occupancy [config=2]
-      wave-slot occupancy proxy of one launch: per-robot cycles (diagnostic build) -> mean / max and the launch's critical robot.
+      The last line (per-robot launch cycles, max / mean) is the wave-slot occupancy proxy of the ticket scheduler: 1.0 = every robot
+      slot is busy until the launch ends.
 
 LMH_DIAG=1 selects liblmh_hip_diag.so (build it with `LMH_DIAG=1 python linearmpchumanoid_amd/build.py`)."""
 import os
