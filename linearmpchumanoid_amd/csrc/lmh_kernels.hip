@@ -50,6 +50,8 @@ typedef const __attribute__((address_space(4))) LmhDevParams LmhCParams;
 // model kernels) degenerates to the single-wave schedule: the join is the wave fence.
 #ifdef LMH_SUBSTAMPS
 __shared__ long long g_bwait[2];     // diagnostic build: cycles each wave of the robot has spent inside workgroup barriers
+__shared__ long long g_jwait[2][12]; // ... split by the join's position inside the evaluation (g_jidx: reset by the rollout loop)
+__shared__ int g_jidx[2];
 #endif
 template <int NW>
 __device__ __forceinline__ void bsync()
@@ -59,7 +61,14 @@ __device__ __forceinline__ void bsync()
 #ifdef LMH_SUBSTAMPS
         const long long t0 = clock64();
         __syncthreads();
-        if ((threadIdx.x & 63u) == 0) g_bwait[threadIdx.x >> 6] += clock64() - t0;
+        if ((threadIdx.x & 63u) == 0) {
+            const int w_ = threadIdx.x >> 6;
+            const long long d_ = clock64() - t0;
+            g_bwait[w_] += d_;
+            const int j_ = g_jidx[w_];
+            g_jwait[w_][j_ < 11 ? j_ : 11] += d_;
+            g_jidx[w_] = j_ + 1;
+        }
 #else
         __syncthreads();
 #endif
@@ -2858,6 +2867,8 @@ __device__ __forceinline__ void kinv_prework(double *L, LmhCParams &P)
     if (ph0 == LMH_PHASE_RIGHT || ph0 == LMH_PHASE_FLIGHT) forced |= 0xFFFF0000u;
     const unsigned Fpub = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)L[P_KF]);
     const unsigned F0 = (P.warm_start ? Fpub : 0xFFFFFFFFu) & ~forced;
+    // the set the stored inverse belongs to has not moved (the usual case from one RK4 stage to the next): nothing to do
+    if (__builtin_amdgcn_readfirstlane((int)(F0 == (unsigned)L[P_KF + 1] && L[P_KF + 2] != 0.0)) != 0) return;
     int st = 0;
     if (F0 != 0xFFFFFFFFu) {                                       // all free: the constant table is used instead
         // a foot with 1..5 free generators has K_f = sum of fewer than six rank-one terms: singular without looking (the usual case in
@@ -2872,7 +2883,7 @@ __device__ __forceinline__ void kinv_prework(double *L, LmhCParams &P)
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
 // PIPE (rollout): the helper wave prepares K_f^-1 at the end of its set-up share instead of at the start of the evaluation, and spends the
 // cone solve -- wave 0 alone -- inside `window` (the next evaluation's clock references and kinematics, lmh_rollout_kernel).
-struct NoWindow { __device__ __forceinline__ void operator()() const {} };
+struct NoWindow { __device__ __forceinline__ void operator()(int) const {} };
 template <int NW, bool F32 = false, bool PIPE = false, class WF = NoWindow>
 __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr, WF window = WF())
 {
@@ -2880,15 +2891,18 @@ __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wi
     int flags;
     if (NW == 2 && wid == 0) { refs_agpqp(L, L[P_MODEL + 392], (P.w_com_ang != 0.0) || (dbgp != nullptr)); WSYNC(); }     // first point where both M (wave 1) and Cg (wave 0) exist
     if constexpr (F32) {
-        if (NW == 2 && wid != 0) { if constexpr (PIPE) window(); bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
+        if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
         flags = qp_setup_f32(L, P);
     } else {
     flags = (P.w_com_ang == 0.0) ? qp_setup15<NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
-    if (PIPE && NW == 2 && wid == 1) kinv_prework(L, P);           // scratch S0 + [2300, 2480): above every array of the set-up
+    if (PIPE && NW == 2 && wid == 1) {
+        kinv_prework(L, P);                                        // scratch S0 + [2300, 2480): above every array of the set-up
+        window(0);                                                 // the part of the look-ahead that needs no scratch
+    }
     WSTAMP(18);
     bsync<NW>();                                                   // Y (helper wave) is complete; the cone solve may overwrite the set-up scratch
     if (NW == 2 && wid != 0) {                                     // the active-set iteration and the recovery are sequential: wave 0
-        if constexpr (PIPE) window();
+        if constexpr (PIPE) window(1);
         WSTAMP(26); bsync<NW>(); WSTAMP(27);
         return 0;
     }
@@ -3326,7 +3340,7 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, d
         for (int e = LANE; e < 91; e += 64) L[P_Q + e] = st[e];    // q | v | v_prev | t
         F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
         F = P.warm_start ? ~F : 0xFFFFFFFFu;                       // status keeps the ACTIVE mask
-        if (LANE == 0) L[P_KF] = (double)F;
+        if (LANE == 0) { L[P_KF] = (double)F; L[P_KF + 2] = 0.0; }             // no K_f^-1 stored yet
         WSYNC();
     }
     bsync<NW>();
@@ -3429,7 +3443,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
         if (lane < 30) L[P_VP + lane] = st[60 + lane];
         F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
         F = P.warm_start ? ~F : 0xFFFFFFFFu;
-        if (lane == 0) L[P_KF] = (double)F;
+        if (lane == 0) { L[P_KF] = (double)F; L[P_KF + 2] = 0.0; }             // no K_f^-1 stored yet
         if constexpr (PIPE) {
             if (lane < 60) L[P_Q + lane] = x;
             WSYNC();
@@ -3441,7 +3455,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     int k = 0, iters = 0, flags = 0, itmax = 0;
     const double dt = P.dt;
 #ifdef LMH_SUBSTAMPS
-    if (lane == 0) g_bwait[wid] = 0;
+    if (lane == 0) { g_bwait[wid] = 0; for (int j_ = 0; j_ < 12; j_++) g_jwait[wid][j_] = 0; }
     const long long t_launch = clock64();
 #endif
     // the leading wave carries the critical path: it wins issue arbitration against the helper wave of the robot it
@@ -3462,13 +3476,17 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             }
             LmhCParams *Pe = Pc;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
-            // wave 1, while wave 0 runs the cone solve and the recovery: the next stage's configuration (rk4_stage, position half), the
-            // clock-only references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick) and its forward
-            // kinematics.  The world transforms land in S0 + [0, 378), which nothing touches until the next evaluation's phase_com_x.
-            auto window = [&]() {
-                rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);
-                if (tn != ts) refs_prepare(L, *Pe, inst, tn);
-                phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
+#ifdef LMH_SUBSTAMPS
+            if (lane == 0) g_jidx[wid] = 0;
+#endif
+            // wave 1, once its share of the QP set-up is done: the next stage's configuration (rk4_stage, position half) and the clock-only
+            // references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick); then, while wave 0 runs the
+            // cone solve and the recovery, its forward kinematics.  The world transforms land in S0 + [0, 378), which nothing touches until the next evaluation's phase_com_x.
+            auto window = [&](int part) {
+                if (part == 0) {                                   // before the join that frees the set-up scratch
+                    rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);
+                    if (tn != ts) refs_prepare(L, *Pe, inst, tn);
+                } else phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
             };
             flags |= controller_eval<2, R, QF32, PIPE, decltype(window)>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3, window);
             if (wid == 0) {
@@ -3488,6 +3506,9 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
         t += dt;                                                    // Clock::step, Clock.hpp:11
     }
     bsync<2>();                                                    // the last torques (helper wave) are in LDS
+#ifdef LMH_SUBSTAMPS
+    if (wid == 1 && lane == 0) st[94] = (double)__builtin_amdgcn_s_getreg(63492);      // HW_ID of wave 1
+#endif
     if (wid == 0) {
         WSYNC();
         store_out(L, out + (size_t)LMH_OUT_STRIDE * inst);
@@ -3495,6 +3516,9 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
         if (lane == 0) {                                           // diagnostic build: this robot's cycles in the launch and inside barriers (pad slots)
             out[(size_t)LMH_OUT_STRIDE * inst + 78] = (double)(clock64() - t_launch);
             st[91] = (double)g_bwait[0]; st[92] = (double)g_bwait[1];
+            for (int j_ = 0; j_ < 12; j_++) { out[(size_t)LMH_OUT_STRIDE * inst + 36 + j_] = (double)g_jwait[0][j_]; out[(size_t)LMH_OUT_STRIDE * inst + 48 + j_] = (double)g_jwait[1][j_]; }
+            st[93] = (double)__builtin_amdgcn_s_getreg(63492);      // HW_ID of wave 0 (SIMD, CU, wave slot) | XCC_ID: where the robot ran
+            st[95] = (double)__builtin_amdgcn_s_getreg(63508);
         }
 #endif
         if (lane < 60) st[lane] = x;

@@ -95,6 +95,37 @@ def barrier(argv):
     print(f"config {cfgno}: {B} robots, {ticks} ticks after {pre}: cycles per evaluation mean {tot.mean()/ev:.0f} (min {tot.min()/ev:.0f}, max {tot.max()/ev:.0f})")
     print(f"  wave 0 inside barriers: {100*(w0/tot).mean():.1f} % ({(w0/ev).mean():.0f} cycles / evaluation);  wave 1: {100*(w1/tot).mean():.1f} % ({(w1/ev).mean():.0f})")
     print(f"  per-robot launch cycles: mean {tot.mean():.0f}  max {tot.max():.0f}  (max / mean = {tot.max()/tot.mean():.3f})")
+    # where the robots ran (HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]; XCC_ID [3:0])
+    h0, h1, xcc = s[:, 93].astype(np.int64), s[:, 94].astype(np.int64), s[:, 95].astype(np.int64) & 15
+    simd0, simd1 = (h0 >> 4) & 3, (h1 >> 4) & 3
+    cu = ((xcc << 8) | (((h0 >> 13) & 7) << 5) | (((h0 >> 12) & 1) << 4) | ((h0 >> 8) & 15))
+    print("  SIMD of (wave 0, wave 1): " + "  ".join(f"({a},{b}): {int(((simd0 == a) & (simd1 == b)).sum())}" for a in range(4) for b in range(4) if ((simd0 == a) & (simd1 == b)).any()))
+    # robots whose leading wave shares its SIMD with another robot's leading wave (same CU, any time: the placement is fixed per workgroup)
+    key = cu * 4 + simd0
+    cnt = {}
+    slot = {}
+    for i in range(B):
+        slot.setdefault((int(cu[i]), int(h0[i] & 15), int(simd0[i])), []).append(i)
+    per_cu = {}
+    for (c, w, sd), robots in slot.items():
+        per_cu.setdefault(c, {}).setdefault(sd, set()).add(w)
+    shared = np.array([len(per_cu[int(cu[i])][int(simd0[i])]) for i in range(B)])
+    for n in sorted(set(shared)):
+        m = shared == n
+        print(f"  leading waves on the robot's SIMD: {n}: {int(m.sum())} robots, cycles / evaluation mean {tot[m].mean()/ev:.0f}")
+    print(f"  CUs seen: {len(per_cu)}")
+    print("  wait per join of an evaluation, cycles (wave 0 | wave 1); the joins in order: X images, tree + references, QP fills, Cm | V, 15 x 15 solve | tiles, Y, recovery:")
+    print("    w0: " + " ".join(f"{v:6.0f}" for v in o[:, 36:48].mean(axis=0) / ev))
+    print("    w1: " + " ".join(f"{v:6.0f}" for v in o[:, 48:60].mean(axis=0) / ev))
+    pc = np.percentile(tot / ev, [1, 10, 50, 90, 99])
+    print("  cycles / evaluation percentiles 1/10/50/90/99: " + " ".join(f"{v:.0f}" for v in pc))
+    for q in range(0, B, 512):
+        seg = tot[q:q + 512] / ev
+        print(f"    robots {q:5d}..{q+511:5d}: mean {seg.mean():.0f} min {seg.min():.0f} max {seg.max():.0f}  w0 wait {(w0[q:q+512]/ev).mean():.0f}  w1 wait {(w1[q:q+512]/ev).mean():.0f}")
+    xs = host.get("xscale") if isinstance(host, dict) else None
+    for x_ in range(8):
+        m = xcc == x_
+        if m.any(): print(f"    XCC {x_}: {int(m.sum())} robots, mean {tot[m].mean()/ev:.0f}")
 
 
 def rounds(argv):
