@@ -49,9 +49,13 @@ typedef const __attribute__((address_space(4))) LmhDevParams LmhCParams;
 // and join at workgroup barriers; the sequential factorisations stay on wave 0.  NW = 1 (the evaluation, IK and
 // model kernels) degenerates to the single-wave schedule: the join is the wave fence.
 #ifdef LMH_SUBSTAMPS
-__shared__ long long g_bwait[2];     // diagnostic build: cycles each wave of the robot has spent inside workgroup barriers
-__shared__ long long g_jwait[2][12]; // ... split by the join's position inside the evaluation (g_jidx: reset by the rollout loop)
-__shared__ int g_jidx[2];
+// diagnostic build: cycles each wave of the robot has spent inside workgroup barriers, in total (D_BWAIT) and split by the join's position
+// inside the evaluation (D_JWAIT; D_JIDX is reset by the rollout loop).  The counters live in a hole of the robot's LDS image (see the map)
+// so that the diagnostic build keeps the shipped kernel's four robots per CU; g_L points at the image.
+__shared__ double *g_L;
+#define D_BWAIT 2290
+#define D_JIDX 2292
+#define D_JWAIT 2294                 // [2][8]
 #endif
 template <int NW>
 __device__ __forceinline__ void bsync()
@@ -64,10 +68,11 @@ __device__ __forceinline__ void bsync()
         if ((threadIdx.x & 63u) == 0) {
             const int w_ = threadIdx.x >> 6;
             const long long d_ = clock64() - t0;
-            g_bwait[w_] += d_;
-            const int j_ = g_jidx[w_];
-            g_jwait[w_][j_ < 11 ? j_ : 11] += d_;
-            g_jidx[w_] = j_ + 1;
+            double *L_ = g_L;
+            L_[D_BWAIT + w_] += (double)d_;
+            const int j_ = (int)L_[D_JIDX + w_];
+            L_[D_JWAIT + 8 * w_ + ((j_ >= 0 && j_ < 7) ? j_ : 7)] += (double)d_;      // slot 7: everything outside the evaluations' seven joins
+            L_[D_JIDX + w_] = (double)(j_ + 1);
         }
 #else
         __syncthreads();
@@ -142,7 +147,8 @@ enum {
     P_GI6 = 2100,     // (G_f G_f')^-1 (6x6)
     P_GPI = 2136,     // G_f' (G_f G_f')^-1 (16x6): min-norm coefficients of a foot wrench
     P_TAU = 2232, P_QDD = 2256,
-    P_TAB = 2286,     // theta offsets (24)
+    P_SCB = 2286,     // sin / cos of pitch and yaw (4), second buffer: the look-ahead kinematics of evaluation n + 1 write one buffer while the
+                      // integrator of evaluation n still reads the other (P_SC + 52 is the first); [2290, 2310): counters of the diagnostic build
     P_POLY = 2310,    // foot polynomials: rF[3][8] | lF[3][8] | counts (6, stored as doubles)
     P_MPCK = 2366,    // MPC record K | Px0 | Px1 (3 (N+1) doubles) when N <= MPC_LDS_MAXN
     P_KI = 2504,      // K_f^-1 of the warm-start free set (2 x 6 x 6), prepared by the helper wave during the kinematics
@@ -207,9 +213,7 @@ enum {
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
     C_LS = S0 + 1440, // 32 x 33 rows of L for the backward substitution
     C_IDX = S0 + 2496, // 32 ints: compact position -> coefficient index
-    P_SCB = S0 + 2512, // sin / cos of pitch and yaw (4), second buffer: the look-ahead kinematics of evaluation n + 1 write one buffer while the
-                       // integrator of evaluation n still reads the other (P_SC + 52 is the first)
-    LDS_DOUBLES = S0 + 2516   // 40928 B + 4 B (ticket) per robot: four robots per CU fill 163.7 of the 163.84 KB
+    LDS_DOUBLES = S0 + 2512   // 40912 B + 4 B (ticket) per robot: four robots per CU fill 163.7 of the 163.84 KB
 };
 
 // -DLMH_POISON (experiment builds only): every robot starts from an LDS image full of NaNs, so that a read of a slot nobody wrote shows up
@@ -715,6 +719,7 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0
         const LV<R> cf = lcoef + 3 * (12 * ((sl < 28) ? sl : 0) + lel);
         c0[u] = cf[0]; ck[u] = cf[ksel];
     }
+    const double dh_off = c_dh_off[(lane < 24) ? lane : 0];        // theta offsets, Robot.cpp:59-87 (constant memory, L2-resident like lcoef)
     R qa = (R)0, qpos = (R)0;
     if constexpr (AHEAD) {                                         // lane permutes, outside the branches
         qa = __shfl(qn, (lane < 24) ? 6 + lane : (lane >= 25 && lane < 28) ? lane - 22 : 0, 64);
@@ -722,8 +727,8 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0
     }
     if (lane < 28) {                                               // one sincos for the 24 joint angles and roll / pitch / yaw
         R x;
-        if constexpr (AHEAD) x = (lane < 24) ? qa + (R)L[P_TAB + lane] : qa;
-        else x = (lane < 24) ? (R)L[P_Q + 6 + lane] + (R)L[P_TAB + lane] : (R)L[P_Q + 3 + ((lane >= 25) ? lane - 25 : 0)];
+        if constexpr (AHEAD) x = (lane < 24) ? qa + (R)dh_off : qa;
+        else x = (lane < 24) ? (R)L[P_Q + 6 + lane] + (R)dh_off : (R)L[P_Q + 3 + ((lane >= 25) ? lane - 25 : 0)];
         R s, c;
         sincos_r(x, &s, &c);
         if (lane == 24) { s = -1.0; c = CPI2; }                    // theta[24] = -pi/2 (Robot.cpp:87)
@@ -2445,8 +2450,10 @@ __device__ __forceinline__ void qp_prefill15(double *L, LmhCParams &P)
 //   * S | d = Mb Y = Mb bp' - (Mb D^-1 U') t'' : Z = Mb D^-1 U' and Mb bp' do not depend on the 15 x 15 solve and are formed by the helper
 //     wave while wave 0 solves; the Y tiles (needed only by the recovery) are formed by the helper wave while wave 0 goes on to S^-1, W, h.
 // NW = 2 joins: fills | Cm, q+V | solve, Z+Mbp | (S..qv), Y | -> the caller's join in front of the cone solve.
-template <int NW>
-__device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, double *dbgp)
+// `slack` (rollout): called by the helper wave where it is ahead of wave 0 -- after its Z / Mb bp' tiles, while wave 0 is in the 15 x 15 solve.
+struct NoWindow { __device__ __forceinline__ void operator()(int) const {} };
+template <int NW, class SF = NoWindow>
+__device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, double *dbgp, SF slack = SF())
 {
     const int lane = LANE;
     int flags = 0;
@@ -2547,6 +2554,7 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
             L[(m < 6) ? Q_Z + 18 * m + tr : Q_TRASH + lane] = zz[g];
             L[(m < 6 && tr < 8) ? Q_MBP + 8 * m + tr : Q_TRASH + lane] = mb[g];
         }
+        if constexpr (NW == 2) slack(0);
     }
     bsync<NW>();
     WSTAMP(16);
@@ -2883,7 +2891,6 @@ __device__ __forceinline__ void kinv_prework(double *L, LmhCParams &P)
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
 // PIPE (rollout): the helper wave prepares K_f^-1 at the end of its set-up share instead of at the start of the evaluation, and spends the
 // cone solve -- wave 0 alone -- inside `window` (the next evaluation's clock references and kinematics, lmh_rollout_kernel).
-struct NoWindow { __device__ __forceinline__ void operator()(int) const {} };
 template <int NW, bool F32 = false, bool PIPE = false, class WF = NoWindow>
 __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr, WF window = WF())
 {
@@ -2894,10 +2901,13 @@ __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wi
         if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
         flags = qp_setup_f32(L, P);
     } else {
-    flags = (P.w_com_ang == 0.0) ? qp_setup15<NW>(L, P, wid, dbgp) : qp_setup<18, NW>(L, P, wid, dbgp);
-    if (PIPE && NW == 2 && wid == 1) {
-        kinv_prework(L, P);                                        // scratch S0 + [2300, 2480): above every array of the set-up
-        window(0);                                                 // the part of the look-ahead that needs no scratch
+    // helper wave, PIPE: K_f^-1 (scratch S0 + [2300, 2480): above every array of the set-up), then the part of the look-ahead that needs no
+    // scratch; where the helper has slack (qp_setup15), else at the end of its share
+    auto slack = [&](int) { if constexpr (PIPE) { kinv_prework(L, P); window(0); } };
+    if (P.w_com_ang == 0.0) flags = qp_setup15<NW, decltype(slack)>(L, P, wid, dbgp, slack);
+    else {
+        flags = qp_setup<18, NW>(L, P, wid, dbgp);
+        if (NW == 2 && wid == 1) slack(0);
     }
     WSTAMP(18);
     bsync<NW>();                                                   // Y (helper wave) is complete; the cone solve may overwrite the set-up scratch
@@ -3263,10 +3273,6 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     return flags;
 }
 
-__device__ __forceinline__ void load_tables(double *L)
-{
-    if (LANE < 24) L[P_TAB + LANE] = c_dh_off[LANE];               // theta offsets, Robot.cpp:59-87
-}
 __device__ __forceinline__ void load_common(double *L, LmhCParams &P, int inst)
 {
     const double *mo = P.model + (size_t)P.model_stride * inst;
@@ -3289,7 +3295,6 @@ __device__ __forceinline__ void load_common(double *L, LmhCParams &P, int inst)
         for (int a = 0; a < 3; a++) { if (q == a) n = P.rFn[a]; if (q == 3 + a) n = P.lFn[a]; }
         L[P_POLY + LANE] = (double)n;
     }
-    load_tables(L);
     if (LANE == 0) {                                               // clock-only reference cache (refs_prepare): empty
         L[P_RK] = -1073741824.0; L[P_RPH] = 0.0; L[P_RT0] = 0.0;
         L[P_RXS] = P.xscale ? P.xscale[inst] : 1.0;                // walking extension: per-instance step length
@@ -3334,6 +3339,10 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, d
     const double t = st[90];
     unsigned F = 0xFFFFFFFFu;
     SET_GDBG(DEBUG ? debug + (size_t)LMH_DEBUG_STRIDE * inst : nullptr);
+#ifdef LMH_SUBSTAMPS
+    if (threadIdx.x == 0) g_L = L;                                 // bsync's wait counters (unused here, but the pointer must be valid)
+    __syncthreads();
+#endif
     LMH_POISON_LDS(L, LDS_DOUBLES);
     if (wid == 0) {
         load_common(L, P, inst);
@@ -3421,6 +3430,10 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     // launch ends when the queue is empty.  Which workgroup runs a robot has no influence on its result (all per-robot state is re-read).
     // The last workgroup to leave (ticket[1] counts them) zeroes both words for the next launch on this slot.
     __shared__ int s_next;
+#ifdef LMH_SUBSTAMPS
+    if (threadIdx.x == 0) g_L = L;                                 // bsync's wait counters live in the robot's LDS image
+    __syncthreads();
+#endif
     const int n_inst = P.n_instances;
     int inst = blockIdx.x;
     while (inst < n_inst) {                                        // workgroup-uniform
@@ -3455,8 +3468,9 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     int k = 0, iters = 0, flags = 0, itmax = 0;
     const double dt = P.dt;
 #ifdef LMH_SUBSTAMPS
-    if (lane == 0) { g_bwait[wid] = 0; for (int j_ = 0; j_ < 12; j_++) g_jwait[wid][j_] = 0; }
-    const long long t_launch = clock64();
+    if (lane == 0) { L[D_BWAIT + wid] = 0.0; for (int j_ = 0; j_ < 8; j_++) L[D_JWAIT + 8 * wid + j_] = 0.0; }
+    __syncthreads();
+    const long long t_launch = clock64(), t_real = wall_clock64();
 #endif
     // the leading wave carries the critical path: it wins issue arbitration against the helper wave of the robot it
     // shares the SIMD with (+2.7 % measured; the reverse assignment gains nothing)
@@ -3477,16 +3491,17 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             LmhCParams *Pe = Pc;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
 #ifdef LMH_SUBSTAMPS
-            if (lane == 0) g_jidx[wid] = 0;
+            if (lane == 0) L[D_JIDX + wid] = 0.0;
 #endif
             // wave 1, once its share of the QP set-up is done: the next stage's configuration (rk4_stage, position half) and the clock-only
             // references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick); then, while wave 0 runs the
             // cone solve and the recovery, its forward kinematics.  The world transforms land in S0 + [0, 378), which nothing touches until the next evaluation's phase_com_x.
             auto window = [&](int part) {
-                if (part == 0) {                                   // before the join that frees the set-up scratch
-                    rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);
+                if (part == 0) rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);        // in the helper's slack inside the QP set-up
+                else {                                             // behind the join that frees the set-up scratch
                     if (tn != ts) refs_prepare(L, *Pe, inst, tn);
-                } else phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
+                    phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
+                }
             };
             flags |= controller_eval<2, R, QF32, PIPE, decltype(window)>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3, window);
             if (wid == 0) {
@@ -3515,8 +3530,9 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
 #ifdef LMH_SUBSTAMPS
         if (lane == 0) {                                           // diagnostic build: this robot's cycles in the launch and inside barriers (pad slots)
             out[(size_t)LMH_OUT_STRIDE * inst + 78] = (double)(clock64() - t_launch);
-            st[91] = (double)g_bwait[0]; st[92] = (double)g_bwait[1];
-            for (int j_ = 0; j_ < 12; j_++) { out[(size_t)LMH_OUT_STRIDE * inst + 36 + j_] = (double)g_jwait[0][j_]; out[(size_t)LMH_OUT_STRIDE * inst + 48 + j_] = (double)g_jwait[1][j_]; }
+            out[(size_t)LMH_OUT_STRIDE * inst + 60] = (double)t_real; out[(size_t)LMH_OUT_STRIDE * inst + 61] = (double)wall_clock64();      // 100 MHz, chip-wide: when the robot came and left
+            st[91] = L[D_BWAIT]; st[92] = L[D_BWAIT + 1];
+            for (int j_ = 0; j_ < 8; j_++) { out[(size_t)LMH_OUT_STRIDE * inst + 36 + j_] = L[D_JWAIT + j_]; out[(size_t)LMH_OUT_STRIDE * inst + 48 + j_] = L[D_JWAIT + 8 + j_]; }
             st[93] = (double)__builtin_amdgcn_s_getreg(63492);      // HW_ID of wave 0 (SIMD, CU, wave slot) | XCC_ID: where the robot ran
             st[95] = (double)__builtin_amdgcn_s_getreg(63508);
         }
@@ -3550,7 +3566,6 @@ __global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double
     const double *rw = raw + (size_t)mi * 28 * LMH_LINK_STRIDE;
     SET_GDBG(nullptr);
     for (int e = lane; e < 30; e += 64) L[P_Q + e] = 0.0;          // FK at q = 0
-    load_tables(L);
     WSYNC();
     phase_fk<double>(L, lcoef);
     double mloc = 0.0;

@@ -115,14 +115,22 @@ def barrier(argv):
         print(f"  leading waves on the robot's SIMD: {n}: {int(m.sum())} robots, cycles / evaluation mean {tot[m].mean()/ev:.0f}")
     print(f"  CUs seen: {len(per_cu)}")
     print("  wait per join of an evaluation, cycles (wave 0 | wave 1); the joins in order: X images, tree + references, QP fills, Cm | V, 15 x 15 solve | tiles, Y, recovery:")
-    print("    w0: " + " ".join(f"{v:6.0f}" for v in o[:, 36:48].mean(axis=0) / ev))
-    print("    w1: " + " ".join(f"{v:6.0f}" for v in o[:, 48:60].mean(axis=0) / ev))
+    print("    w0: " + " ".join(f"{v:6.0f}" for v in o[:, 36:44].mean(axis=0) / ev))
+    print("    w1: " + " ".join(f"{v:6.0f}" for v in o[:, 48:56].mean(axis=0) / ev))
     pc = np.percentile(tot / ev, [1, 10, 50, 90, 99])
     print("  cycles / evaluation percentiles 1/10/50/90/99: " + " ".join(f"{v:.0f}" for v in pc))
     for q in range(0, B, 512):
         seg = tot[q:q + 512] / ev
         print(f"    robots {q:5d}..{q+511:5d}: mean {seg.mean():.0f} min {seg.min():.0f} max {seg.max():.0f}  w0 wait {(w0[q:q+512]/ev).mean():.0f}  w1 wait {(w1[q:q+512]/ev).mean():.0f}")
-    xs = host.get("xscale") if isinstance(host, dict) else None
+    dur = o[:, 61] - o[:, 60]
+    span = o[:, 61].max() - o[:, 60].min()
+    print(f"  launch makespan {span/100:.0f} us (100 MHz clock); sum of robot times / 1024 slots = {dur.sum()/1024/100:.0f} us: slot occupancy {dur.sum()/1024/span:.3f};  robot time mean {dur.mean()/100:.0f} max {dur.max()/100:.0f} us")
+    top = np.argsort(-tot)[:12]
+    print("  slowest robots: " + "  ".join(f"{int(i)}:{tot[i]/ev:.0f}(cu {int(cu[i])} simd {int(simd0[i])},{int(simd1[i])} rounds {int(status[int(i),1])})" for i in top))
+    st_ = status.cpu().numpy()
+    for r_ in sorted(set(st_[:, 1])):
+        m = st_[:, 1] == r_
+        print(f"    max QP rounds {int(r_)}: {int(m.sum())} robots, cycles / evaluation mean {tot[m].mean()/ev:.0f}")
     for x_ in range(8):
         m = xcc == x_
         if m.any(): print(f"    XCC {x_}: {int(m.sum())} robots, mean {tot[m].mean()/ev:.0f}")
