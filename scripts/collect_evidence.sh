@@ -7,8 +7,8 @@ for f in bench_r03_c3 bench_r03_c2 bench_r03_c5 bench_r03_c3_coupled bench_r03_c
 [ -s gpurun_out/r03_barrier_share.txt ] && grep -v amdgpu gpurun_out/r03_barrier_share.txt > profiles/r03_barrier_share.txt
 [ -s gpurun_out/r03_qp_rounds.txt ] && grep -v amdgpu gpurun_out/r03_qp_rounds.txt > profiles/r03_qp_rounds.txt
 if [ -s gpurun_out/tl_ds.txt ]; then
-  { echo "== double support (LMH_DIAG=1 LMH_DIAG_NW2=1 python scripts/diag.py timeline 3 1120) =="; grep -v amdgpu gpurun_out/tl_ds.txt; echo
-    echo "== single support (python scripts/diag.py timeline 3 1300) =="; grep -v amdgpu gpurun_out/tl_ss.txt; } > profiles/r03_wave_timeline.txt
+  { echo "== evaluation after 1120 ticks (LMH_DIAG=1 LMH_DIAG_NW2=1 python scripts/diag.py timeline 3 1120; the first line names the support phase) =="; grep -v amdgpu gpurun_out/tl_ds.txt; echo
+    echo "== evaluation after 1300 ticks (python scripts/diag.py timeline 3 1300) =="; grep -v amdgpu gpurun_out/tl_ss.txt; } > profiles/r03_wave_timeline.txt
 fi
 [ -s gpurun_out/r03_phase_stamps.txt ] && grep -v amdgpu.ids gpurun_out/r03_phase_stamps.txt > profiles/r03_phase_stamps.txt
 [ -s gpurun_out/r03_precision_sweep.json ] && cp gpurun_out/r03_precision_sweep.json profiles/

@@ -398,6 +398,23 @@ def test_bench_precision_2_and_config5_lines():
     assert r5["config"]["preview_s"] == pytest.approx(0.48) and r5["cpu_baseline"]["parity_vs_gpu_last_tick_max_rel"] < 1e-6
 
 
+def test_bench_config5_on_two_ranks_over_gloo():
+    """N > 1 readiness of the config-5 entry point (BASELINE configs[4] is quoted on 8 GPUs): `bench.py --gpus 2 --config 5` starts two
+    ranks of itself (both on card 0 of a one-GPU box, gloo), each takes its shard of the jumpers, the summary rows of both come back in
+    the one gather, no instance is flagged, and the line says what ran."""
+    env_dev = os.environ.get("LMH_BENCH_DEVICE")
+    os.environ["LMH_BENCH_DEVICE"] = "0"
+    try:
+        res = _run_bench(["--gpus", "2", "--backend", "gloo", "--config", "5", "--instances", "128", "--steps", "2", "--warmup", "1", "--ticks", "700",
+                          "--no-cpu-baseline"])
+    finally:
+        if env_dev is None: os.environ.pop("LMH_BENCH_DEVICE", None)
+        else: os.environ["LMH_BENCH_DEVICE"] = env_dev
+    assert res["n_gpus"] == 2 and res["summary_rows_gathered"] == 256 and res["instances_flagged"] == 0
+    assert res["config"]["baseline_config"] == 5 and res["scaling"] == "weak" and "jump" in res["config"]["workload"]
+    assert res["config"]["parallelism"].endswith("x2") and res["value"] > 0
+
+
 def test_config4_decoupled_randomised_walkers(nao):
     """BASELINE configs[3] at one GPU's share in the decoupled form bench.py --config 4 runs per rank: 4096 randomised models (IK
     kernel start postures, per-instance LIPM height and step length), dt = 1 ms, N = 32 x 10 ms, 0.5 s steps: 1 500 ticks
