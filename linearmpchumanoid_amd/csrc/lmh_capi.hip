@@ -47,7 +47,7 @@ struct lmh_handle {
     static constexpr int kSlots = 8;
     struct Slot {
         LmhDevParams *d_P = nullptr;  // device copy read by the rollout kernel
-        int *d_ticket = nullptr;      // robot queue + departure count (two ints, zero between launches: the kernel resets them)
+        int *d_ticket = nullptr;      // work-unit counters, ring queue of robots, ticks done per robot (4 + 2 B ints, all zero between launches: the kernel leaves them so)
         hipEvent_t done = nullptr;    // recorded behind the last launch that used this slot
         LmhDevParams P_dev;           // what d_P currently holds
         bool valid = false, used = false;
@@ -512,8 +512,9 @@ extern "C" int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_
     lmh_handle::Slot &sl = h->slot[h->next_slot++ % lmh_handle::kSlots];
     if (!sl.d_P) {
         HIPCHK(hipMalloc(&sl.d_P, sizeof(LmhDevParams)));
-        HIPCHK(hipMalloc(&sl.d_ticket, 2 * sizeof(int)));
-        HIPCHK(hipMemset(sl.d_ticket, 0, 2 * sizeof(int)));
+        const size_t tbytes = (4 + 2 * (size_t)h->P.n_instances) * sizeof(int);   // counters | ring of robots | ticks done per robot
+        HIPCHK(hipMalloc(&sl.d_ticket, tbytes));
+        HIPCHK(hipMemset(sl.d_ticket, 0, tbytes));
         HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     if (sl.used) HIPCHK(hipEventSynchronize(sl.done));              // the launch that last used this slot (kSlots launches ago) has left it

@@ -3402,6 +3402,9 @@ __device__ __forceinline__ void rk4_stage(const double *L, int stage, int lane, 
 // Workgroup = LMH_ROLLOUT_THREADS = 2 waves per robot (see bsync): 4 robots = 8 waves per CU, two per SIMD, so the
 // kernel is held to 256 registers.  Wave 0 owns the RK4 state (lane i < 60 <-> component i) and everything
 // sequential; wave 1 joins for the phases controller_eval<2> splits.
+#ifndef LMH_CHUNK_TICKS
+#define LMH_CHUNK_TICKS 250          // ticks of one robot a workgroup runs before the robot goes back to the queue (see lmh_rollout_kernel)
+#endif
 template <typename R, bool QF32 = false>
 #ifndef LMH_ROLLOUT_ATTR
 #ifndef LMH_WAVES_PER_EU
@@ -3425,18 +3428,26 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     // One workgroup runs several robots one after the other (grid = the number of workgroups the chip holds at once, lmh_launch_rollout):
     // when the hardware dispatcher refills the chip from a longer grid, throughput drops by ~15 % (measured: 1024 robots 4.1 ms per launch,
     // 2048 robots 11.4 ms, 4096 robots 19.2 ms for the same 40 ticks); looping inside the resident workgroups keeps the first round's placement.
-    // The first robot of a workgroup is its block index; every further one is drawn from a global ticket (ticket[0], one atomicAdd per
-    // robot): a workgroup whose robots finish early (fewer QP rounds) takes the next one instead of idling behind a static stride, and the
-    // launch ends when the queue is empty.  Which workgroup runs a robot has no influence on its result (all per-robot state is re-read).
-    // The last workgroup to leave (ticket[1] counts them) zeroes both words for the next launch on this slot.
-    __shared__ int s_next;
+    // The unit of work is (robot, chunk of LMH_CHUNK_TICKS ticks): a robot's state goes back to its HBM record at the end of a chunk and the
+    // robot re-enters a ring queue, so the launch does not end with most workgroups idle behind the few that drew a slow robot last
+    // (whole-robot units left the slots busy 97.6 % of a launch).  Work units are claimed with one atomicAdd on `head`; claims below
+    // n_inst - grid are the robots nobody has touched yet (no memory traffic), the others wait for the claim's ring entry to be pushed --
+    // by a workgroup that is running, never by one that waits, so the wait ends (the number of pushes equals the number of such claims).
+    // Which workgroup runs a chunk has no influence on its result: everything per-robot is re-read from the record, the caches in LDS are
+    // rebuilt from it.  ticket: [0] head | [1] workgroups that left | [2] tail | [3] - | ring [n_inst] (robot + 1, 0 = empty) | ticks done [n_inst].
+    // The last workgroup to leave zeroes the counters for the next launch on this slot (ring and progress entries zero themselves).
+    __shared__ int s_next, s_tick0;
 #ifdef LMH_SUBSTAMPS
     if (threadIdx.x == 0) g_L = L;                                 // bsync's wait counters live in the robot's LDS image
     __syncthreads();
 #endif
     const int n_inst = P.n_instances;
-    int inst = blockIdx.x;
-    while (inst < n_inst) {                                        // workgroup-uniform
+    int *const ring = ticket + 4, *const prog = ticket + 4 + n_inst;
+    const int n_chunks = (n_ticks + LMH_CHUNK_TICKS - 1) / LMH_CHUNK_TICKS;
+    const long long n_claims = (long long)n_inst * n_chunks - (long long)gridDim.x;      // work units beyond each workgroup's first
+    int inst = blockIdx.x, tick0 = 0;
+    while (inst >= 0 && inst < n_inst) {                           // workgroup-uniform
+    const int n_here = (n_ticks - tick0 < LMH_CHUNK_TICKS) ? n_ticks - tick0 : LMH_CHUNK_TICKS;
     const int lane = LANE;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double *st = state + (size_t)LMH_STATE_STRIDE * inst;
@@ -3466,6 +3477,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     bsync<2>();
     if (PIPE && wid == 1) refs_prepare(L, P, inst, t);             // clock-only references of the first evaluation (needs load_common's cache reset)
     int k = 0, iters = 0, flags = 0, itmax = 0;
+    if (tick0 > 0) { itmax = status[LMH_STATUS_STRIDE * inst + 1]; flags = status[LMH_STATUS_STRIDE * inst + 2]; }      // status[1], [2] cover the whole launch
     const double dt = P.dt;
 #ifdef LMH_SUBSTAMPS
     if (lane == 0) { L[D_BWAIT + wid] = 0.0; for (int j_ = 0; j_ < 8; j_++) L[D_JWAIT + 8 * wid + j_] = 0.0; }
@@ -3475,7 +3487,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     // the leading wave carries the critical path: it wins issue arbitration against the helper wave of the robot it
     // shares the SIMD with (+2.7 % measured; the reverse assignment gains nothing)
     if (wid == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-    for (int tick = 0; tick < n_ticks; tick++) {
+    for (int tick = 0; tick < n_here; tick++) {
         double ksum = 0.0, xs = x;
         for (int stage = 0; stage < 4; stage++) {
             const double ts = (stage == 0) ? t : (stage == 3) ? t + dt : t + 0.5 * dt;      // rk4.hpp:12-15
@@ -3514,7 +3526,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             }
         }
         if (log) {                                                  // each wave logs what it produced: wave 1 the torques, wave 0 the wrench
-            double *lg = log + ((size_t)tick * P.n_instances + inst) * 36;
+            double *lg = log + ((size_t)(tick0 + tick) * P.n_instances + inst) * 36;
             if (wid != 0) { if (lane < 24) lg[lane] = L[P_TAU + lane]; }
             else if (lane >= 24 && lane < 36) lg[lane] = L[P_W12 + lane - 24];
         }
@@ -3545,13 +3557,46 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             s[0] = k; s[1] = itmax; s[2] = flags; s[3] = (int32_t)(~F);
         }
     }
-    if (threadIdx.x == 0) s_next = (int)gridDim.x + atomicAdd(&ticket[0], 1);
-    __syncthreads();                                               // also: every lane is done with this robot's LDS image
+    __syncthreads();                                               // every store of the record has left both waves; every lane is done with the LDS image
+    if (threadIdx.x == 0) {
+        int next = -1, next0 = 0;
+        __threadfence();                                           // the record is visible before the robot is
+        if (tick0 + n_here < n_ticks) {
+            prog[inst] = tick0 + n_here;
+            __threadfence();
+            const int tpos = atomicAdd(&ticket[2], 1);
+            atomicExch(&ring[tpos % n_inst], inst + 1);
+        } else prog[inst] = 0;
+        const long long n = (long long)atomicAdd(&ticket[0], 1);
+        if (n < n_claims) {
+            const long long fresh = (long long)n_inst - (long long)gridDim.x;
+            if (n < fresh) next = (int)gridDim.x + (int)n;
+            else {
+                int *slot = ring + (int)((n - fresh) % n_inst);
+                int v = 0;
+                for (int spin = 0; spin < (1 << 26); spin++) {     // bounded: a lost push must not hang the chip (the robot then stays unfinished, visibly)
+                    v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != 0) break;
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                if (v != 0) {
+                    atomicExch(slot, 0);
+                    __threadfence();
+                    next = v - 1;
+                    next0 = __hip_atomic_load(&prog[next], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        s_next = next; s_tick0 = next0;
+    }
+    __syncthreads();
     inst = __builtin_amdgcn_readfirstlane(s_next);
-    }                                                              // next robot of this workgroup (the next write of s_next is many barriers away)
-    if (threadIdx.x == 0) {                                        // every draw of this workgroup precedes this increment: the last one to leave resets the slot
+    tick0 = __builtin_amdgcn_readfirstlane(s_tick0);
+    __threadfence();                                               // acquire: this CU's vector cache may hold the record as it was chunks ago
+    }                                                              // next work unit of this workgroup (the next write of s_next is many barriers away)
+    if (threadIdx.x == 0) {                                        // every claim of this workgroup precedes this increment: the last one to leave resets the slot
         __threadfence();
-        if (atomicAdd(&ticket[1], 1) == (int)gridDim.x - 1) { ticket[0] = 0; ticket[1] = 0; __threadfence(); }
+        if (atomicAdd(&ticket[1], 1) == (int)gridDim.x - 1) { ticket[0] = 0; ticket[1] = 0; ticket[2] = 0; __threadfence(); }
     }
 }
 
