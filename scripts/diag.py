@@ -122,7 +122,7 @@ def barrier(argv):
     for q in range(0, B, 512):
         seg = tot[q:q + 512] / ev
         print(f"    robots {q:5d}..{q+511:5d}: mean {seg.mean():.0f} min {seg.min():.0f} max {seg.max():.0f}  w0 wait {(w0[q:q+512]/ev).mean():.0f}  w1 wait {(w1[q:q+512]/ev).mean():.0f}")
-    dur = o[:, 61] - o[:, 60]
+    dur = o[:, 62]                                                  # busy time summed over the robot's chunks
     span = o[:, 61].max() - o[:, 60].min()
     print(f"  launch makespan {span/100:.0f} us (100 MHz clock); sum of robot times / 1024 slots = {dur.sum()/1024/100:.0f} us: slot occupancy {dur.sum()/1024/span:.3f};  robot time mean {dur.mean()/100:.0f} max {dur.max()/100:.0f} us")
     top = np.argsort(-tot)[:12]

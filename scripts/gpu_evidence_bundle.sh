@@ -20,7 +20,8 @@ if [ $PART = bench ] || [ $PART = all ]; then
 fi
 if [ $PART = diag ] || [ $PART = all ]; then
   export LMH_DIAG=1
-  timeout -k 10 300 python scripts/diag.py barrier 3 200 1300 > gpurun_out/r03_barrier_share.txt 2>&1
+  timeout -k 10 300 python scripts/diag.py barrier 3 1000 1000 > gpurun_out/r03_barrier_share.txt 2>&1
+  timeout -k 10 300 python scripts/diag.py barrier 3 200 1300 >> gpurun_out/r03_barrier_share.txt 2>&1
   timeout -k 10 300 python scripts/diag.py barrier 3 200 1100 >> gpurun_out/r03_barrier_share.txt 2>&1
   timeout -k 10 300 python scripts/diag.py barrier 2 200 600 >> gpurun_out/r03_barrier_share.txt 2>&1
   timeout -k 10 300 python scripts/diag.py barrier 5 200 600 >> gpurun_out/r03_barrier_share.txt 2>&1

@@ -365,6 +365,40 @@ def test_ticket_scheduling_is_result_neutral_and_reusable(nao):
         assert np.array_equal(o3.cpu().numpy(), ref_out) and np.array_equal(s3.cpu().numpy(), ref_st)
 
 
+def test_chunked_work_units_equal_a_sequence_of_short_launches(nao):
+    """Inside one launch a robot is run in chunks of 250 ticks and goes back to a ring queue in between (another workgroup may take the
+    next chunk).  A 620-tick launch of 1500 robots (more than the resident grid: fresh robots and ring entries both occur; pushes
+    make the QP round counts uneven) must equal, bit for bit, three launches of 250 + 250 + 120 ticks: state, out record and log
+    rows; status[0] (k) and [3] (active set) are those of the last tick, [1] the maximum and [2] the OR over the whole launch.
+    Launching again on the same handle (queue words back at zero) reproduces it."""
+    B, N = 1500, 16
+    v = perturbed_velocities(B, seed=777)
+    ctl = make_controller(B, N, nao["zcom"], mpc_dt=2e-2, warm_start=1)
+    ctl.set_refs_stance(2.0, 2)
+    for rep in range(2):
+        st = ctl.new_state(nao["q0"], v, t=0.0)
+        log = torch.zeros((620, B, 36), dtype=torch.float64, device=ctl.device)
+        out, status, _ = ctl.rollout(st, 620, log=log)
+        torch.cuda.synchronize()
+        st2 = ctl.new_state(nao["q0"], v, t=0.0)
+        out2, status2 = ctl.new_out(), ctl.new_status()
+        itmax = np.zeros(B, dtype=np.int64); flags = np.zeros(B, dtype=np.int64)
+        logs = []
+        for n in (250, 250, 120):
+            lg = torch.zeros((n, B, 36), dtype=torch.float64, device=ctl.device)
+            ctl.rollout(st2, n, out2, status2, lg)
+            torch.cuda.synchronize()
+            s_ = status2.cpu().numpy()
+            itmax = np.maximum(itmax, s_[:, 1]); flags |= s_[:, 2]
+            logs.append(lg.cpu().numpy())
+        a, b = status.cpu().numpy(), status2.cpu().numpy()
+        assert np.array_equal(st.cpu().numpy(), st2.cpu().numpy()) and np.array_equal(out.cpu().numpy(), out2.cpu().numpy())
+        assert np.array_equal(log.cpu().numpy(), np.concatenate(logs, axis=0))
+        assert np.array_equal(a[:, 0], b[:, 0]) and np.array_equal(a[:, 3], b[:, 3])
+        assert np.array_equal(a[:, 1], itmax) and np.array_equal(a[:, 2], flags)
+        assert (a[:, 2] == 0).all() and a[:, 1].max() > 1
+
+
 # ------------------------------------------------------------------------------- bench.py: flag accounting, precision 2, config 5
 def _run_bench(argv, expect_rc=0, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
