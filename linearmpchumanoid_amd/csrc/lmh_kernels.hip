@@ -700,15 +700,11 @@ __device__ __forceinline__ void sincos_r(float x, float *s, float *c) { sincosf(
 // generalizedFunctions.cpp:52-72).  Reads L[P_Q], writes A_T (30 x 3x4) and L[P_SC].
 // AHEAD (helper wave of the rollout, inside the previous evaluation): the configuration comes from a register (lane i < 30 holds q_i)
 // instead of L[P_Q], the roll / pitch / yaw terms go to scratch, and the four the integrator reads (sin / cos of pitch and yaw) to `xd4`.
-// PART (AHEAD only): 1 = the trigonometric half alone (needs no scratch: the helper runs it in its slack ahead of the join that frees the
-// scratch when the cone solve is going to be short), 2 = the rest, 0 = both.
-#define P_SRN (P_TIME + 0)         // sin, cos of the look-ahead roll (pitch and yaw sit in the integrator's double buffer)
-#define P_CRN (P_TIME + 4)
-template <typename R, bool AHEAD = false, int PART = 0>
+template <typename R, bool AHEAD = false>
 __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0, int xd4 = P_SC + 52)
 {
     const int lane = LANE;
-    static_assert(AHEAD || PART == 0, "the split form belongs to the look-ahead");
+    constexpr int RPY = AHEAD ? (int)A_T0S + 12 : (int)P_SC + 50;
     // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos
     // lane = (slot fr < 5, entry el < 12): five of the 28 local transforms per round, six rounds
     const int lfr = (lane < 60) ? lane / 12 : 0, lel = lane % 12;
@@ -717,36 +713,31 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0
     const bool cosT = (lel == 0) || (lel == 5) || (lel == 9);
     const int ksel = cosT ? 1 : 2;
     R c0[6], ck[6];
-    if constexpr (PART != 1) {
 #pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const int sl = 5 * u + lfr;
-            const LV<R> cf = lcoef + 3 * (12 * ((sl < 28) ? sl : 0) + lel);
-            c0[u] = cf[0]; ck[u] = cf[ksel];
-        }
+    for (int u = 0; u < 6; u++) {
+        const int sl = 5 * u + lfr;
+        const LV<R> cf = lcoef + 3 * (12 * ((sl < 28) ? sl : 0) + lel);
+        c0[u] = cf[0]; ck[u] = cf[ksel];
     }
-    if constexpr (PART != 2) {
-        const double dh_off = c_dh_off[(lane < 24) ? lane : 0];    // theta offsets, Robot.cpp:59-87 (constant memory, L2-resident like lcoef)
-        R qa = (R)0;
-        if constexpr (AHEAD) qa = __shfl(qn, (lane < 24) ? 6 + lane : (lane >= 25 && lane < 28) ? lane - 22 : 0, 64);      // lane permute, outside the branch
-        if (lane < 28) {                                           // one sincos for the 24 joint angles and roll / pitch / yaw
-            R x;
-            if constexpr (AHEAD) x = (lane < 24) ? qa + (R)dh_off : qa;
-            else x = (lane < 24) ? (R)L[P_Q + 6 + lane] + (R)dh_off : (R)L[P_Q + 3 + ((lane >= 25) ? lane - 25 : 0)];
-            R s, c;
-            sincos_r(x, &s, &c);
-            if (lane == 24) { s = -1.0; c = CPI2; }                // theta[24] = -pi/2 (Robot.cpp:87)
-            if constexpr (AHEAD) {
-                const int so = (lane < 25) ? P_SC + 2 * lane : (lane == 25) ? (int)P_SRN : xd4 + 2 * (lane - 26);
-                const int co = (lane < 25) ? P_SC + 2 * lane + 1 : (lane == 25) ? (int)P_CRN : xd4 + 2 * (lane - 26) + 1;
-                L[so] = s; L[co] = c;
-            } else { L[P_SC + 2 * lane] = s; L[P_SC + 2 * lane + 1] = c; }
-        }
-        WSYNC();
+    const double dh_off = c_dh_off[(lane < 24) ? lane : 0];        // theta offsets, Robot.cpp:59-87 (constant memory, L2-resident like lcoef)
+    R qa = (R)0, qpos = (R)0;
+    if constexpr (AHEAD) {                                         // lane permutes, outside the branches
+        qa = __shfl(qn, (lane < 24) ? 6 + lane : (lane >= 25 && lane < 28) ? lane - 22 : 0, 64);
+        qpos = __shfl(qn, (lane < 12) ? (lane >> 2) : 0, 64);
     }
-    if constexpr (PART == 1) return;
-    R qpos = (R)0;
-    if constexpr (AHEAD) qpos = __shfl(qn, (lane < 12) ? (lane >> 2) : 0, 64);
+    if (lane < 28) {                                               // one sincos for the 24 joint angles and roll / pitch / yaw
+        R x;
+        if constexpr (AHEAD) x = (lane < 24) ? qa + (R)dh_off : qa;
+        else x = (lane < 24) ? (R)L[P_Q + 6 + lane] + (R)dh_off : (R)L[P_Q + 3 + ((lane >= 25) ? lane - 25 : 0)];
+        R s, c;
+        sincos_r(x, &s, &c);
+        if (lane == 24) { s = -1.0; c = CPI2; }                    // theta[24] = -pi/2 (Robot.cpp:87)
+        const int so = (lane < 25) ? P_SC + 2 * lane : RPY + 2 * (lane - 25);
+        L[so] = s;
+        L[so + 1] = c;
+        if (AHEAD && lane >= 26) { L[xd4 + 2 * (lane - 26)] = s; L[xd4 + 2 * (lane - 26) + 1] = c; }
+    }
+    WSYNC();
     SUBSTAMP(0);
     WSTAMP(44);
     // local transforms (Khalil DH, Robot.cpp:200-214 + the fixed transforms / offsets of :92-154): every entry is
@@ -763,9 +754,7 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0
     }
     if (lane < 12) {                                               // T0 = [R(rpy) p]
         const int r = lane >> 2, col = lane & 3;
-        R sr, cr, sp, cp, sy, cy;
-        if constexpr (AHEAD) { sr = L[P_SRN]; cr = L[P_CRN]; sp = L[xd4]; cp = L[xd4 + 1]; sy = L[xd4 + 2]; cy = L[xd4 + 3]; }
-        else { sr = L[P_SC + 50]; cr = L[P_SC + 51]; sp = L[P_SC + 52]; cp = L[P_SC + 53]; sy = L[P_SC + 54]; cy = L[P_SC + 55]; }
+        const R sr = L[RPY + 0], cr = L[RPY + 1], sp = L[RPY + 2], cp = L[RPY + 3], sy = L[RPY + 4], cy = L[RPY + 5];
         R val;
         if (col == 3) { if constexpr (AHEAD) val = qpos; else val = L[P_Q + r]; }
         else if (r == 0) val = (col == 0) ? cy * cp : (col == 1) ? cy * sp * sr - sy * cr : cy * sp * cr + sy * sr;
@@ -2920,7 +2909,6 @@ __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wi
         flags = qp_setup<18, NW>(L, P, wid, dbgp);
         if (NW == 2 && wid == 1) slack(0);
     }
-    if (PIPE && NW == 2 && wid == 1) window(2);
     WSTAMP(18);
     bsync<NW>();                                                   // Y (helper wave) is complete; the cone solve may overwrite the set-up scratch
     if (NW == 2 && wid != 0) {                                     // the active-set iteration and the recovery are sequential: wave 0
@@ -3514,25 +3502,17 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             }
             LmhCParams *Pe = Pc;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
-            bool trig_early = false;
 #ifdef LMH_SUBSTAMPS
             if (lane == 0) L[D_JIDX + wid] = 0.0;
 #endif
             // wave 1, once its share of the QP set-up is done: the next stage's configuration (rk4_stage, position half) and the clock-only
             // references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick); then, while wave 0 runs the
             // cone solve and the recovery, its forward kinematics.  The world transforms land in S0 + [0, 378), which nothing touches until the next evaluation's phase_com_x.
-            // In double support the cone solve is the short all-free one and the helper's window behind it would be the longer side: there
-            // the trigonometric half of the kinematics (no scratch needed) runs ahead of the join, in the helper's slack behind its Y tiles.
             auto window = [&](int part) {
                 if (part == 0) rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);        // in the helper's slack inside the QP set-up
-                else if (part == 2) {                              // just before the join that frees the set-up scratch
-                    const int ph_ = __builtin_amdgcn_readfirstlane((int)L[P_RPH]);
-                    trig_early = (ph_ == LMH_PHASE_DOUBLE) || (ph_ == LMH_PHASE_FLIGHT);
-                    if (trig_early) phase_fk<R, true, 1>(L, Pe->gcol + 228, (R)xs, xd4n);
-                } else {                                           // behind it
+                else {                                             // behind the join that frees the set-up scratch
                     if (tn != ts) refs_prepare(L, *Pe, inst, tn);
-                    if (trig_early) phase_fk<R, true, 2>(L, Pe->gcol + 228, (R)xs, xd4n);
-                    else phase_fk<R, true, 0>(L, Pe->gcol + 228, (R)xs, xd4n);
+                    phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
                 }
             };
             flags |= controller_eval<2, R, QF32, PIPE, decltype(window)>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3, window);
