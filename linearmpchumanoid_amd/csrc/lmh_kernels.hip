@@ -3367,6 +3367,31 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, d
     }
 }
 
+// One claim on the rollout's work queue (called by one thread of the workgroup): -1 when no unit is left, else the robot, with the ticks it has
+// behind it in *tick0.  Claims below n_inst are the robots' first chunks (no memory traffic); the others wait for their ring entry, which
+// is pushed by a workgroup that is RUNNING a chunk of that robot -- no workgroup owns a unit it has not claimed, so the queue drains with any
+// number of resident workgroups >= 1 (two launches sharing the chip, a debugger, a partitioned device).
+__device__ __forceinline__ int rollout_claim(int *ticket, int n_inst, long long n_units, int *tick0)
+{
+    int *const ring = ticket + 4, *const prog = ticket + 4 + n_inst;
+    *tick0 = 0;
+    const long long n = (long long)atomicAdd(&ticket[0], 1);
+    if (n >= n_units) return -1;
+    if (n < (long long)n_inst) return (int)n;
+    int *slot = ring + (int)((n - n_inst) % n_inst);
+    int v = 0;
+    for (int spin = 0; spin < (1 << 26); spin++) {                 // bounded: a lost push must not hang the chip (the robot then stays unfinished, visibly)
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (v == 0) return -1;
+    atomicExch(slot, 0);
+    __threadfence();
+    *tick0 = __hip_atomic_load(&prog[v - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v - 1;
+}
+
 // One stage of rk4Step (rk4.hpp:5-18) for state component `lane` < 60 (q | v): xdot of apps/offline/main.cpp:107-121 from the evaluation that
 // has just run, then the stage bookkeeping -- ksum collects k1 + 2 k2 + 2 k3 + k4, xs is the state of the next evaluation, x the state at the
 // start of the tick (advanced by the fourth stage).  `xd4`: LDS index of sin / cos of pitch and yaw of THIS evaluation's configuration.
@@ -3430,12 +3455,11 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     // 2048 robots 11.4 ms, 4096 robots 19.2 ms for the same 40 ticks); looping inside the resident workgroups keeps the first round's placement.
     // The unit of work is (robot, chunk of LMH_CHUNK_TICKS ticks): a robot's state goes back to its HBM record at the end of a chunk and the
     // robot re-enters a ring queue, so the launch does not end with most workgroups idle behind the few that drew a slow robot last
-    // (whole-robot units left the slots busy 97.6 % of a launch).  Work units are claimed with one atomicAdd on `head`; claims below
-    // n_inst - grid are the robots nobody has touched yet (no memory traffic), the others wait for the claim's ring entry to be pushed --
-    // by a workgroup that is running, never by one that waits, so the wait ends (the number of pushes equals the number of such claims).
-    // Which workgroup runs a chunk has no influence on its result: everything per-robot is re-read from the record, the caches in LDS are
-    // rebuilt from it.  ticket: [0] head | [1] workgroups that left | [2] tail | [3] - | ring [n_inst] (robot + 1, 0 = empty) | ticks done [n_inst].
-    // The last workgroup to leave zeroes the counters for the next launch on this slot (ring and progress entries zero themselves).
+    // (whole-robot units left the slots busy 97.6 % of a launch).  Every unit, a workgroup's first included, is claimed with one atomicAdd
+    // on `head` (rollout_claim).  Which workgroup runs a chunk has no influence on its result: everything per-robot is re-read from the
+    // record, the caches in LDS are rebuilt from it.  ticket: [0] head | [1] workgroups that left | [2] tail | [3] - | ring [n_inst]
+    // (robot + 1, 0 = empty) | ticks done [n_inst].  The last workgroup to leave zeroes the counters for the next launch on this slot (ring
+    // and progress entries zero themselves).
     __shared__ int s_next, s_tick0;
 #ifdef LMH_SUBSTAMPS
     if (threadIdx.x == 0) g_L = L;                                 // bsync's wait counters live in the robot's LDS image
@@ -3444,8 +3468,10 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     const int n_inst = P.n_instances;
     int *const ring = ticket + 4, *const prog = ticket + 4 + n_inst;
     const int n_chunks = (n_ticks + LMH_CHUNK_TICKS - 1) / LMH_CHUNK_TICKS;
-    const long long n_claims = (long long)n_inst * n_chunks - (long long)gridDim.x;      // work units beyond each workgroup's first
-    int inst = blockIdx.x, tick0 = 0;
+    const long long n_units = (long long)n_inst * n_chunks;
+    if (threadIdx.x == 0) { int t0_ = 0; s_next = rollout_claim(ticket, n_inst, n_units, &t0_); s_tick0 = t0_; }
+    __syncthreads();
+    int inst = __builtin_amdgcn_readfirstlane(s_next), tick0 = __builtin_amdgcn_readfirstlane(s_tick0);
     while (inst >= 0 && inst < n_inst) {                           // workgroup-uniform
     const int n_here = (n_ticks - tick0 < LMH_CHUNK_TICKS) ? n_ticks - tick0 : LMH_CHUNK_TICKS;
     const int lane = LANE;
@@ -3567,7 +3593,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     }
     __syncthreads();                                               // every store of the record has left both waves; every lane is done with the LDS image
     if (threadIdx.x == 0) {
-        int next = -1, next0 = 0;
+        int next0 = 0;
         __threadfence();                                           // the record is visible before the robot is
         if (tick0 + n_here < n_ticks) {
             prog[inst] = tick0 + n_here;
@@ -3575,26 +3601,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             const int tpos = atomicAdd(&ticket[2], 1);
             atomicExch(&ring[tpos % n_inst], inst + 1);
         } else prog[inst] = 0;
-        const long long n = (long long)atomicAdd(&ticket[0], 1);
-        if (n < n_claims) {
-            const long long fresh = (long long)n_inst - (long long)gridDim.x;
-            if (n < fresh) next = (int)gridDim.x + (int)n;
-            else {
-                int *slot = ring + (int)((n - fresh) % n_inst);
-                int v = 0;
-                for (int spin = 0; spin < (1 << 26); spin++) {     // bounded: a lost push must not hang the chip (the robot then stays unfinished, visibly)
-                    v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v != 0) break;
-                    __builtin_amdgcn_s_sleep(16);
-                }
-                if (v != 0) {
-                    atomicExch(slot, 0);
-                    __threadfence();
-                    next = v - 1;
-                    next0 = __hip_atomic_load(&prog[next], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
+        const int next = rollout_claim(ticket, n_inst, n_units, &next0);
         s_next = next; s_tick0 = next0;
     }
     __syncthreads();

@@ -397,6 +397,19 @@ def test_chunked_work_units_equal_a_sequence_of_short_launches(nao):
         assert np.array_equal(a[:, 0], b[:, 0]) and np.array_equal(a[:, 3], b[:, 3])
         assert np.array_equal(a[:, 1], itmax) and np.array_equal(a[:, 2], flags)
         assert (a[:, 2] == 0).all() and a[:, 1].max() > 1
+    # two multi-chunk launches sharing the chip (two streams, two launch slots of the handle): neither has all of its workgroups resident
+    # from the start, and no workgroup owns a unit it has not claimed, so both drain; results as above
+    ref_state, ref_out = st.cpu().numpy().copy(), out.cpu().numpy().copy()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    res = []
+    for sm in streams:
+        with torch.cuda.stream(sm):
+            s3 = ctl.new_state(nao["q0"], v, t=0.0)
+            o3, t3, _ = ctl.rollout(s3, 620)
+            res.append((s3, o3))
+    torch.cuda.synchronize()
+    for s3, o3 in res:
+        assert np.array_equal(s3.cpu().numpy(), ref_state) and np.array_equal(o3.cpu().numpy(), ref_out)
 
 
 # ------------------------------------------------------------------------------- bench.py: flag accounting, precision 2, config 5
