@@ -213,7 +213,11 @@ enum {
     C_P = S0 + 384,   // 32 x 33 (padded rows: conflict-free row-per-lane reads)
     C_LS = S0 + 1440, // 32 x 33 rows of L for the backward substitution
     C_IDX = S0 + 2496, // 32 ints: compact position -> coefficient index
+#ifdef LMH_LDS_PROBE_DOUBLES
+    LDS_DOUBLES = LMH_LDS_PROBE_DOUBLES   // occupancy probe builds only (scripts/occupancy_probe.py): such a library is queried, never launched
+#else
     LDS_DOUBLES = S0 + 2512   // 40912 B + 4 B (ticket) per robot: four robots per CU fill 163.7 of the 163.84 KB
+#endif
 };
 
 // -DLMH_POISON (experiment builds only): every robot starts from an LDS image full of NaNs, so that a read of a slot nobody wrote shows up
@@ -4029,7 +4033,18 @@ static int rollout_resident_groups()
     }
     return cached[dev];
 }
-// d_ticket: two zero-initialised ints of device memory owned by this launch until it completes (robot queue + departures, see the kernel)
+// Diagnostic (scripts/occupancy_probe.py): what the runtime's occupancy calculator and the code object say about lmh_rollout_kernel<double>:
+// workgroups per CU, architected registers per lane, static LDS per workgroup.  Not part of the C ABI of include/lmh.h.
+extern "C" int lmh_debug_rollout_occupancy(int *groups_per_cu, int *num_regs, int *static_lds_bytes)
+{
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&lmh_rollout_kernel<double, false>)) != hipSuccess) return -1;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lmh_rollout_kernel<double, false>, LMH_ROLLOUT_THREADS, 0) != hipSuccess) return -2;
+    *groups_per_cu = nb; *num_regs = at.numRegs; *static_lds_bytes = (int)at.sharedSizeBytes;
+    return 0;
+}
+// d_ticket: zero-initialised device memory owned by this launch until it completes (work-unit counters, ring, progress: see the kernel)
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, int *d_ticket, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)
 {
     const int slots = rollout_resident_groups();
