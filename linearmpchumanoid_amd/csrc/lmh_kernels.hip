@@ -3401,10 +3401,15 @@ __device__ __forceinline__ int rollout_claim(int *ticket, int n_inst, long long 
 // start of the tick (advanced by the fourth stage).  `xd4`: LDS index of sin / cos of pitch and yaw of THIS evaluation's configuration.
 // The position half (lane < 30) reads nothing the evaluation produces, which is what lets the helper wave call this ahead of wave 0
 // (its lanes >= 30 then hold don't-cares).
-__device__ __forceinline__ void rk4_stage(const double *L, int stage, int lane, double dt, int xd4, double &x, double &ksum, double &xs)
+// XDQ: 0 = plain; 1 = (helper wave, ahead) also leave the position half of xdot in L[P_XDQ]; 2 = (wave 0, behind the helper) take it from there
+// instead of forming it again -- three fp64 divisions and the cross product leave wave 0's path between two evaluations.
+#define P_XDQ P_AG                 // 30 doubles: the angular rows of AG are dead once the QP fills have read the references
+template <int XDQ = 0>
+__device__ __forceinline__ void rk4_stage(double *L, int stage, int lane, double dt, int xd4, double &x, double &ksum, double &xs)
 {
     double xd = 0.0;
-    if (lane < 60) {
+    if (XDQ == 2 && lane < 60) xd = (lane >= 30) ? L[P_QDD + lane - 30] : L[P_XDQ + lane];
+    else if (lane < 60) {
         if (lane >= 30) xd = L[P_QDD + lane - 30];
         else if (lane >= 6) xd = L[P_V + lane];
         else if (lane < 3) {
@@ -3421,6 +3426,7 @@ __device__ __forceinline__ void rk4_stage(const double *L, int stage, int lane, 
                              : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
         }
     }
+    if (XDQ == 1 && lane < 30) L[P_XDQ + lane] = xd;
     if (stage == 0) { ksum = xd; xs = x + 0.5 * dt * xd; }                              // rk4.hpp:12-17
     else if (stage == 1) { ksum = ksum + 2.0 * xd; xs = x + 0.5 * dt * xd; }
     else if (stage == 2) { ksum = ksum + 2.0 * xd; xs = x + dt * xd; }
@@ -3539,7 +3545,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             // references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick); then, while wave 0 runs the
             // cone solve and the recovery, its forward kinematics.  The world transforms land in S0 + [0, 378), which nothing touches until the next evaluation's phase_com_x.
             auto window = [&](int part) {
-                if (part == 0) rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);        // in the helper's slack inside the QP set-up
+                if (part == 0) rk4_stage<1>(L, stage, lane, dt, xd4, x, ksum, xs);     // in the helper's slack inside the QP set-up
                 else {                                             // behind the join that frees the set-up scratch
                     if (tn != ts) refs_prepare(L, *Pe, inst, tn);
                     phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
@@ -3549,7 +3555,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
                 const double xprev = xs;
-                rk4_stage(L, stage, lane, dt, xd4, x, ksum, xs);
+                if constexpr (PIPE) rk4_stage<2>(L, stage, lane, dt, xd4, x, ksum, xs); else rk4_stage<0>(L, stage, lane, dt, xd4, x, ksum, xs);
                 // Robot::v_ <- dq for the next evaluation
                 WSYNC();
                 if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xprev;
