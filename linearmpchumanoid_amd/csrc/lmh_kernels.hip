@@ -3374,7 +3374,8 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, d
 // One claim on the rollout's work queue (called by one thread of the workgroup): -1 when no unit is left, else the robot, with the ticks it has
 // behind it in *tick0.  Claims below n_inst are the robots' first chunks (no memory traffic); the others wait for their ring entry, which
 // is pushed by a workgroup that is RUNNING a chunk of that robot -- no workgroup owns a unit it has not claimed, so the queue drains with any
-// number of resident workgroups >= 1 (two launches sharing the chip, a debugger, a partitioned device).
+// number of resident workgroups >= 1 (two launches sharing the chip, a debugger, a partitioned device).  The protocol is modelled under
+// random schedules in tests/test_host_logic.py::test_rollout_work_queue_protocol_drains_under_any_schedule.
 __device__ __forceinline__ int rollout_claim(int *ticket, int n_inst, long long n_units, int *tick0)
 {
     int *const ring = ticket + 4, *const prog = ticket + 4 + n_inst;
@@ -3608,8 +3609,12 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
         if (tick0 + n_here < n_ticks) {
             prog[inst] = tick0 + n_here;
             __threadfence();
-            const int tpos = atomicAdd(&ticket[2], 1);
-            atomicExch(&ring[tpos % n_inst], inst + 1);
+            const int tpos = atomicAdd(&ticket[2], 1);             // the position is reserved; the entry goes in once the slot is empty: the taker of
+            int *pslot = ring + tpos % n_inst;                     // the entry one lap earlier (a running workgroup, spinning on it) may not have been there yet
+            for (int spin = 0; spin < (1 << 26); spin++) {
+                if (atomicCAS(pslot, 0, inst + 1) == 0) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
         } else prog[inst] = 0;
         const int next = rollout_claim(ticket, n_inst, n_units, &next0);
         s_next = next; s_tick0 = next0;

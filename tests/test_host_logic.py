@@ -234,3 +234,59 @@ def test_create_rejects_values_the_kernels_would_divide_by(hip_lib):
     assert rc == (0 if torch.cuda.is_available() else -1)
     if h.value:
         hip_lib.lmh_destroy(h)
+
+
+def test_rollout_work_queue_protocol_drains_under_any_schedule():
+    """Model of the rollout kernel's work queue (lmh_kernels.hip: rollout_claim + the push at the end of a chunk), run under random
+    interleavings with FEWER runners than workgroups of the grid resident at a time: every (robot, chunk) unit is executed exactly once
+    and in order per robot, no runner waits for ever, and the counters / ring are back at zero.  The invariant the kernel relies on: a
+    claim beyond the robots' first chunks waits for a ring entry that only a RUNNING workgroup can push."""
+    import random
+    for seed, (n_inst, n_chunks, grid, resident) in enumerate([(7, 3, 4, 2), (16, 5, 8, 8), (5, 1, 5, 3), (9, 4, 12, 1), (32, 6, 8, 5), (3, 9, 6, 4)] * 8):
+        rng = random.Random(seed)
+        head = tail = 0
+        ring = [0] * n_inst
+        prog = [0] * n_inst
+        done = [[] for _ in range(n_inst)]
+        n_units = n_inst * n_chunks
+        # a workgroup: state machine 'claim' -> ('wait', slot) -> ('run', robot, chunk) -> ('push', slot, robot) -> 'claim' ... -> 'gone'
+        wgs = ["new"] * grid
+        running = set()
+        steps = 0
+        while any(w != "gone" for w in wgs):
+            steps += 1
+            assert steps < 200000, "the queue does not drain"
+            # the hardware keeps at most `resident` workgroups on the chip; one that has started stays until it leaves
+            cand = [i for i, w in enumerate(wgs) if w != "gone" and (i in running or len(running) < resident)]
+            i = rng.choice(cand)
+            running.add(i)
+            w = wgs[i]
+            if w == "new" or w == "claim":
+                n = head; head += 1
+                if n >= n_units:
+                    wgs[i] = "gone"; running.discard(i)
+                elif n < n_inst:
+                    wgs[i] = ("run", n, 0)
+                else:
+                    wgs[i] = ("wait", (n - n_inst) % n_inst)
+            elif w[0] == "push":                                   # (a slow taker of the entry one lap earlier may still hold the slot)
+                if ring[w[1]] == 0:
+                    ring[w[1]] = w[2] + 1
+                    wgs[i] = "claim"
+            elif w[0] == "wait":
+                v = ring[w[1]]
+                if v:
+                    ring[w[1]] = 0
+                    wgs[i] = ("run", v - 1, prog[v - 1])
+            else:
+                _, r, c = w
+                assert len(done[r]) == c                           # chunks of a robot run in order, one at a time
+                done[r].append(c)
+                if c + 1 < n_chunks:
+                    prog[r] = c + 1
+                    wgs[i] = ("push", tail % n_inst, r); tail += 1  # the position is reserved; the entry goes in once the slot is empty
+                else:
+                    prog[r] = 0
+                    wgs[i] = "claim"
+        assert all(d == list(range(n_chunks)) for d in done)
+        assert not any(ring) and not any(prog) and tail == n_inst * (n_chunks - 1) and head == n_units + grid
