@@ -146,7 +146,9 @@ def rounds(argv):
         ctl.rollout(state, chunk, out, status)
         s = status.cpu().numpy()
         nF = np.array([bin((~int(x)) & 0xFFFFFFFF).count("1") for x in s[:, 3]])
-        print(f"ticks {c*chunk:5d}..{(c+1)*chunk:5d}: max rounds per launch mean {s[:,1].mean():5.2f} max {s[:,1].max():3d}  flagged {int((s[:,2] != 0).sum()):5d}  |F| mean {nF.mean():5.1f}  |v|max {float(state[:, 30:60].abs().max()):.2f}")
+        fl = s[:, 2]
+        kinds = " ".join(f"{name}:{int(((fl >> b) & 1).sum())}" for b, name in enumerate(("QP_MAXITER", "NONFINITE", "ZMP_RANGE", "NOT_SPD", "FP64_ROUTE")) if ((fl >> b) & 1).any())
+        print(f"ticks {c*chunk:6d}..{(c+1)*chunk:6d}: max rounds per launch mean {s[:,1].mean():5.2f} max {s[:,1].max():3d}  flagged {int((fl != 0).sum()):5d} {kinds}  |F| mean {nF.mean():5.1f}  |v|max {float(state[:, 30:60].abs().max()):.2f}  base x {float(state[:, 0].min()):.2f}..{float(state[:, 0].max()):.2f}")
 
 
 if __name__ == "__main__":

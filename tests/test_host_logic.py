@@ -142,12 +142,12 @@ def test_bench_defaults_name_the_largest_single_gpu_config():
     rollout segment, nothing restarted; --gpus N > 1 one GPU's share of configs[3]; --coupled keeps rounds 1-2's line."""
     b, _ = _bench_mod()
     a = b.parse([])
-    assert (a.config, a.instances, a.horizon, a.gpus, a.ticks, a.mpc_dt, a.reset_every) == (3, 4096, 32, 1, 4000, 1e-2, 0)
+    assert (a.config, a.instances, a.horizon, a.gpus, a.ticks, a.mpc_dt, a.reset_every) == (3, 4096, 32, 1, 4000, 1e-2, 10)
     assert (a.step_time, a.ds_time) == (0.5, 0.2)                   # the reference's default timePerStep (zmpGeneration.hpp:37-38)
     assert a.horizon * a.mpc_dt >= 0.32 - 1e-12                     # a preview the LIPM loop is stable with
     assert a.steps * a.ticks * a.instances / 20e6 >= 3.0            # timed region >= 3 s even at 20 M ticks/s
     d = b.parse(["--steps", "20", "--warmup", "5"])                 # the driver's flags
-    assert d.ticks == 4000 and d.reset_every == 0
+    assert d.ticks == 4000 and d.reset_every == 10
     a8 = b.parse(["--gpus", "8"])
     assert (a8.config, a8.instances, a8.ticks) == (4, 4096, 4000)
     a2 = b.parse(["--config", "2"])
