@@ -190,7 +190,11 @@ int lmh_eval_debug(lmh_handle *h, double *d_state, double *d_out, int32_t *d_sta
 /* replaces: the closed loop of apps/offline/main.cpp:66-122 (rk4Step, rk4.hpp:5-18, of
  * dynamics(); Clock::step, Clock.hpp:11) for n_ticks ticks, state resident on chip.
  * d_out receives the k4-stage evaluation of the last tick; d_log (optional, DEVICE
- * [n_ticks][B][36]) receives tau|f of the k4 stage of every tick.  Asynchronous. */
+ * [n_ticks][B][36]) receives tau|f of the k4 stage of every tick.  d_status: [0] k and [3] the active set of the last
+ * tick, [1] the maximum of the QP rounds and [2] the OR of the flags over ALL ticks of the call.  Asynchronous.
+ * Inside the call a robot is advanced in chunks of 250 ticks by whichever resident workgroup claims it next (its record in
+ * d_state / d_out / d_status is the hand-over); the result does not depend on that: lmh_rollout(.., a + b, ..) equals
+ * lmh_rollout(.., a, ..) followed by lmh_rollout(.., b, ..) bit for bit (with [1], [2] merged as max / OR). */
 int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, double *d_log,
                 int n_ticks, void *stream);
 
