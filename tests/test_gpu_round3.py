@@ -368,7 +368,7 @@ def test_ticket_scheduling_is_result_neutral_and_reusable(nao):
 def test_chunked_work_units_equal_a_sequence_of_short_launches(nao):
     """Inside one launch a robot is run in chunks of 250 ticks and goes back to a ring queue in between (another workgroup may take the
     next chunk).  A 620-tick launch of 1500 robots (more than the resident grid: fresh robots and ring entries both occur; pushes
-    make the QP round counts uneven) must equal, bit for bit, three launches of 250 + 250 + 120 ticks: state, out record and log
+    make the QP round counts uneven) must equal, bit for bit, three launches of 250 + 250 + 120 ticks (the kernel's own chunk boundaries) and two of 100 + 520: state, out record and log
     rows; status[0] (k) and [3] (active set) are those of the last tick, [1] the maximum and [2] the OR over the whole launch.
     Launching again on the same handle (queue words back at zero) reproduces it."""
     B, N = 1500, 16
@@ -384,7 +384,7 @@ def test_chunked_work_units_equal_a_sequence_of_short_launches(nao):
         out2, status2 = ctl.new_out(), ctl.new_status()
         itmax = np.zeros(B, dtype=np.int64); flags = np.zeros(B, dtype=np.int64)
         logs = []
-        for n in (250, 250, 120):
+        for n in ((250, 250, 120) if rep == 0 else (100, 520)):     # split at the kernel's own chunk boundaries, and elsewhere
             lg = torch.zeros((n, B, 36), dtype=torch.float64, device=ctl.device)
             ctl.rollout(st2, n, out2, status2, lg)
             torch.cuda.synchronize()
