@@ -46,7 +46,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak = 256 CU x 64 lanes x
 FP64_MFMA_PEAK_TFLOPS = 78.6     # v_mfma_f64_16x16x4_f64: fp64 matrix rate = fp64 vector rate on gfx950
 MFMA_MOP_FLOP = 512              # SQ_INSTS_VALU_MFMA_MOPS_F64 unit (one 16x16x4 f64 MFMA = 2048 flop = 4 MOPS)
 PROFILE_TAGS = {3: "r03_c3", 2: "r03_c2"}   # profiles/<tag>_rollout_summary.json: PMC passes of the committed kernel on the default command
-HARD_FLAGS = 1 | 2 | 4 | 8       # LMH_FLAG_QP_MAXITER | NONFINITE | ZMP_RANGE | NOT_SPD; LMH_FLAG_QP_FP64_ROUTE (16) is informational
+HARD_FLAGS = 1 | 2 | 4 | 8 | 32  # LMH_FLAG_QP_MAXITER | NONFINITE | ZMP_RANGE | NOT_SPD | UNFINISHED; LMH_FLAG_QP_FP64_ROUTE (16) is informational
 
 # One step = `ticks` ticks in one launch.  mpc_dt: MPC sample time / reference sample period (lmh_config.mpc_dt); the preview spans
 # horizon x mpc_dt = 0.32 s (0.48 s for the jump) -- with the preview tied to the 1 ms control step (16..48 ms, far below the LIPM's time
@@ -72,8 +72,8 @@ COUPLED_WALK = dict(step_time=0.2, ds_time=0.05, settle_time=0.1)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)         # 8 launches x ~1.4 s on the default workload
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None)      # default 8 launches x ~1.2 s on the default workload (--mode eval: 200 launches of ~0.1 ms)
+    ap.add_argument("--warmup", type=int, default=None)     # default 2 (--mode eval: 20)
     ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5),
                     help="BASELINE config number (1-based); default 3 at --gpus 1, 4 (randomised models + IK kernel in set-up) otherwise")
     ap.add_argument("--coupled", action="store_true", help="rounds 1-2's line: mpc_dt = dt, short steps, rollouts restarted inside their validity range")
@@ -99,12 +99,20 @@ def parse(argv=None):
     ap.add_argument("--push", type=float, default=None, help="config 2: amplitude factor on SURVEY's U(-0.3, 0.3) m/s pushes")
     ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2), help="lmh_config.precision (0 fp64, 1 mixed, 2 fp32)")
     ap.add_argument("--max-qp-iters", type=int, default=None, help="diagnostic: lmh_config.max_qp_iters (a low cap raises LMH_FLAG_QP_MAXITER: exercises the flag accounting / exit code 3)")
+    ap.add_argument("--mode", default="rollout", choices=("rollout", "eval"),
+                    help="rollout (default, the headline): fused closed loop; eval: the SECONDARY lines of the evaluation API -- lmh_eval "
+                         "(= Controller::standStep + WBC, src/controller.cpp:48-154) for all robots per control step, and B = 1 through "
+                         "lmh_eval_host as the shim's Controller drives it from apps/offline/main.cpp:66-89")
     ap.add_argument("--host-io", action="store_true",
                     help="informational: every step also moves the state host->device and out | status | log device->host through pinned "
                          "buffers (what a caller holding HOST buffers pays over PCIe); never the default line")
     args = ap.parse_args(argv)
     if args.config is None:
         args.config = 3 if args.gpus == 1 else 4
+    if args.steps is None:
+        args.steps = 200 if args.mode == "eval" else 8
+    if args.warmup is None:
+        args.warmup = 20 if args.mode == "eval" else 2
     if args.coupled and args.config == 5:
         ap.error("--coupled has no config 5 line")
     d = dict((COUPLED if args.coupled else DEFAULTS)[args.config])
@@ -374,6 +382,105 @@ def profiled_pmc(args):
         return None
 
 
+# ------------------------------------------------------------------------------------------------ evaluation API (secondary lines)
+ALG_BYTES_PER_EVAL = 1008        # SURVEY 8d, eval-API mode: 60 f64 in + 66 f64 out per instance per evaluation
+
+
+def main_eval(args, ctl, state, host, count):
+    """bench.py --mode eval (N = 1 only).  (a) lmh_eval on all `count` robots of the configured workload: one step = one launch = one
+    controller evaluation per robot, at a double-support and at a single-support state of the walk (reached by the rollout kernel,
+    untimed); evaluations/s, HBM roofline on SURVEY 8d's 1 008 B per evaluation, the per-launch time.  (b) B = 1 through lmh_eval_host
+    -- host buffers in, H2D, kernel, D2H, synchronous -- four calls per tick exactly as the shim's Controller::standStep is driven by
+    rk4Step in apps/offline/main.cpp:66-89 at the reference's literals (dt = 0.01, N = 50), beside the C oracle on one core."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from linearmpchumanoid_amd import capi
+    from linearmpchumanoid_amd.controller import BatchedController, default_config, ik_start_posture
+    out, status = ctl.new_out(), ctl.new_status()
+    lines = {}
+    pos = 0
+    for name, upto in (("double_support", 400), ("single_support", 700)):       # WALK: settle 0.3 s, DS 0.2 s, SS 0.3 s
+        ctl.rollout(state, upto - pos, out, status)
+        pos = upto
+        st = state.clone()
+        for _ in range(args.warmup):
+            ctl.stand_step(st, out, status)
+        torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            ctl.stand_step(st, out, status)                        # the same instant again: v_prev and the warm start carry over, like rk4's stages 2 | 3
+        ev1.record()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kms = ev0.elapsed_time(ev1) / args.steps
+        flagged = int(((status[:, 2] & HARD_FLAGS) != 0).sum().item())
+        lines[name] = dict(evaluations_per_s=count * args.steps / el, launch_ms=kms, wall_ms_per_launch=el / args.steps * 1e3,
+                           support_phase=int(host["phase"][int(status[0, 0].item())]) if host.get("phase") is not None else 0, instances_flagged=flagged)
+    ss = lines["single_support"]
+    hbm_g = count * ALG_BYTES_PER_EVAL / (ss["launch_ms"] * 1e-3) / 1e9
+    fl = count * ALG_FLOP_PER_TICK / 4 / (ss["launch_ms"] * 1e-3) / 1e12
+    # (b) B = 1, host buffers, reference literals
+    q0, zcom = ik_start_posture(ctl.device_index)
+    c1 = BatchedController(1, default_config(dt=0.01, time_horizon=0.5, z_com=zcom), device=ctl.device_index)
+    c1.set_refs_stance(5.0, 2)
+    L = capi.lib()
+    q = np.ascontiguousarray(q0); dq = np.zeros(30); tau = np.zeros(24); f = np.zeros(12); qdd = np.zeros(30); stt = np.zeros(4, np.int32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    n_ticks = 200
+    def tick(t):
+        for ts in (t, t + 0.005, t + 0.005, t + 0.01):             # rk4.hpp:12-15: four evaluations per tick (the state advance itself is ~100 flops on the host)
+            capi.check(L.lmh_eval_host(c1._h, ptr(q), ptr(dq), C.c_double(ts), ptr(tau), ptr(f), ptr(qdd), ptr(stt)))
+    for i in range(20):
+        tick(0.01 * i)
+    t0 = time.perf_counter()
+    for i in range(n_ticks):
+        tick(0.01 * i)
+    b1 = (time.perf_counter() - t0) / n_ticks
+    res_b1 = {"ms_per_tick": b1 * 1e3, "ms_per_evaluation": b1 * 250.0, "ticks_per_s": 1.0 / b1,
+              "path": "lmh_eval_host, B = 1: memcpy of q | dq into the staged record, hipMemcpy H2D, lmh_eval_kernel (one workgroup), three hipMemcpy D2H (state, out, status), "
+                      "all synchronous -- what the shim's Controller::standStep costs per call (apps/offline/main.cpp:66-89 through csrc/shim)",
+              "config": "reference literals: dt = 0.01, N = 50, stance, IK posture"}
+    app = os.path.join(ROOT, "apps", "offline_stand")
+    if os.path.exists(app):                                        # the whole app, process start / lmh_create / IK included: 5 s of stand = 500 ticks
+        t0 = time.perf_counter()
+        r = subprocess.run([app, "5", "0.01", "0.5"], capture_output=True, text=True)
+        res_b1["offline_stand_app"] = {"wall_s": time.perf_counter() - t0, "ticks": len(r.stdout.split()), "returncode": r.returncode,
+                                       "last_com_x": float(r.stdout.split()[-1]) if r.stdout.split() else None}
+    if not args.no_cpu_baseline:
+        from oracle.pyoracle import Oracle
+        o = Oracle(sim_time=5.0, dt=0.01, horizon_time=0.5, do_ik=True)
+        x0 = np.concatenate([o.robot()["q"], np.zeros(30)])
+        o.rollout(x0, 0.0, 20)
+        t0 = time.perf_counter()
+        ro = o.rollout(x0, 0.0, n_ticks)
+        ob = (time.perf_counter() - t0) / n_ticks
+        model, logical, usable, quota = host_cpu_info()
+        res_b1["cpu_oracle_single_core"] = {"ms_per_tick": ob * 1e3, "ticks_per_s": 1.0 / ob, "cores": 1, "kind": "port", "cpu_model": model,
+                                            "sample": f"C oracle, 1 robot x {n_ticks} ticks of the same stand at the reference literals (one WBC solve per evaluation)",
+                                            "last_com_x": float(ro["comx"][-1])}
+    res = {
+        "metric": "controller evaluations/s (lmh_eval: batched Controller::standStep + WBC)",
+        "value": ss["evaluations_per_s"], "unit": "evaluations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ss["wall_ms_per_launch"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "secondary_line": True,
+        "config": {"workload": WORKLOAD_TEXT[args.config].format(B=count, dt=args.dt, N=args.horizon, md=args.mpc_dt, push=args.push, st=args.step_time)
+                               + "; one step = ONE lmh_eval launch (one controller evaluation per robot) at the single-support state reached after 700 ticks",
+                   "baseline_config": args.config, "instances_per_gpu": count, "mode": "eval"},
+        "by_support_phase": lines,
+        "roofline": {"bound": "hbm", "achieved": hbm_g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_g / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "lmh_eval_kernel", "kernel_ms": ss["launch_ms"], "units_per_launch": count, "algorithmic_bytes_per_launch": count * ALG_BYTES_PER_EVAL,
+                     "note": "SURVEY 8d's eval-API figure (1 008 B per evaluation) on the HBM axis as asked; the kernel is bound by fp64 issue + LDS latency like the rollout, "
+                             "and every launch also re-reads the robot's model / tables (3.1 KB + 1.8 KB, L2-resident) and rebuilds the LDS image the rollout keeps across 250 ticks",
+                     "fp64_valu": {"achieved": fl, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / FP64_VALU_PEAK_TFLOPS, "nominal_flop_per_evaluation": ALG_FLOP_PER_TICK / 4}},
+        "b1_host_path": res_b1,
+    }
+    print(json.dumps(res), flush=True)
+    sys.exit(3 if any(v["instances_flagged"] for v in lines.values()) else 0)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -395,9 +502,13 @@ def main():
     from linearmpchumanoid_amd.controller import BatchedController, default_config
     from linearmpchumanoid_amd import sharding
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     if os.environ.get("LMH_BENCH_DEVICE") is not None:          # rehearsal of N>1 on a one-GPU box (gloo): all ranks share a card
         local_rank = int(os.environ["LMH_BENCH_DEVICE"])
+    n_dev = torch.cuda.device_count()                             # (counting devices does not initialise the GPU)
+    if local_rank >= n_dev:
+        sys.exit(f"bench.py: LOCAL_RANK={local_rank} but only {n_dev} GPU(s) are visible to this process: one rank per GPU of ONE node "
+                 f"(--gpus N needs N visible devices; there is no CPU fallback for the product path)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)                             # before the process group: RCCL binds its communicator to this device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -413,10 +524,14 @@ def main():
         cfg.max_qp_iters = args.max_qp_iters
     ctl = BatchedController(count, cfg, device=local_rank)
     assert ctl.N == args.horizon, (ctl.N, args.horizon)
-    n_launch = args.warmup + args.steps
+    n_launch = (args.warmup + args.steps) if args.mode == "rollout" else 1
     reset_every = max(0, args.reset_every)                         # 0: consecutive steps continue the same rollouts
     total_ticks = (min(n_launch, reset_every) if reset_every else n_launch) * args.ticks
     state, host = build_workload(args, ctl, first, count, total_ticks)
+    if args.mode == "eval":
+        if world != 1 or args.config not in (3, 4):
+            sys.exit("bench.py --mode eval: one GPU, a walking configuration (--config 3 or 4)")
+        main_eval(args, ctl, state, host, count)                   # never returns
     state0 = state.clone()
     out, status = ctl.new_out(), ctl.new_status()
     log = None if args.no_log else torch.zeros((args.ticks, count, 36), dtype=torch.float64, device=ctl.device)
@@ -425,6 +540,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        ctl.synchronize()                                          # lmh_synchronize: an incomplete launch (LMH_ERR_UNFINISHED) is an error here, not a number
 
     done = 0
     flags_acc = torch.zeros((count,), dtype=torch.int32, device=ctl.device)   # status flags OR-ed over EVERY launch (the kernel overwrites status[:, 2] per launch)

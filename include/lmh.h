@@ -49,6 +49,8 @@ extern "C" {
 #define LMH_FLAG_NONFINITE 2      /* NaN/Inf in the solution (reference aborts, controller.cpp:448-466) */
 #define LMH_FLAG_ZMP_RANGE 4      /* preview window [k, k+N] left the reference arrays */
 #define LMH_FLAG_NOT_SPD 8        /* a Cholesky pivot was not positive */
+#define LMH_FLAG_UNFINISHED 32    /* lmh_rollout only: a wait of the kernel's work queue ran out and this robot did not get all its ticks (its state / out
+                                   * records are those of the last chunk it completed); the call reports LMH_ERR_UNFINISHED, see lmh_rollout */
 #define LMH_FLAG_QP_FP64_ROUTE 16 /* LMH_PRECISION_FP32 only, informational: a contact-force solve of this instance met a rank-deficient free set
                                    * (or the Lawson-Hanson pass) and went the fp64 general route -- that system (cond ~1e13) has no fp32 form */
 
@@ -69,7 +71,8 @@ enum {
     LMH_ERR_NO_DEVICE = -1,
     LMH_ERR_BAD_ARG = -2,
     LMH_ERR_HIP = -3,
-    LMH_ERR_NOT_READY = -4
+    LMH_ERR_NOT_READY = -4,
+    LMH_ERR_UNFINISHED = -5       /* an earlier lmh_rollout on this handle left robots part-way (LMH_FLAG_UNFINISHED in their status records) */
 };
 
 /* Literals of the reference, gathered in one record (the reference has no config layer):
@@ -194,7 +197,14 @@ int lmh_eval_debug(lmh_handle *h, double *d_state, double *d_out, int32_t *d_sta
  * tick, [1] the maximum of the QP rounds and [2] the OR of the flags over ALL ticks of the call.  Asynchronous.
  * Inside the call a robot is advanced in chunks of 250 ticks by whichever resident workgroup claims it next (its record in
  * d_state / d_out / d_status is the hand-over); the result does not depend on that: lmh_rollout(.., a + b, ..) equals
- * lmh_rollout(.., a, ..) followed by lmh_rollout(.., b, ..) bit for bit (with [1], [2] merged as max / OR). */
+ * lmh_rollout(.., a, ..) followed by lmh_rollout(.., b, ..) bit for bit (with [1], [2] merged as max / OR).
+ * Host side of "asynchronous": the call only enqueues (one small parameter copy + the kernel) on `stream`, except that a handle keeps
+ * EIGHT launches in flight -- the ninth lmh_rollout waits on the host until the first has completed -- and that the first eight calls
+ * allocate their launch slot (hipMalloc): not capturable into a hipGraph before every slot has been used once.
+ * Incomplete launches are loud: the queue's waits are bounded, and if one runs out (a workgroup stalled for minutes: preemption, a
+ * debugger) the robots that did not get all their ticks carry LMH_FLAG_UNFINISHED in d_status[.][2], and lmh_synchronize -- or the next
+ * lmh_rollout that reuses the launch slot -- returns LMH_ERR_UNFINISHED once (the reference prints and aborts, src/controller.cpp:448-476).
+ * The launch slot is clean again afterwards; the caller decides whether to re-run those robots. */
 int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, double *d_log,
                 int n_ticks, void *stream);
 
@@ -220,6 +230,7 @@ int lmh_last_out_host(lmh_handle *h, double *out);
 int lmh_ik_host(lmh_handle *h, double *q, const double *com_target, const double *rf6, const double *lf6, double *com, int32_t *iters);
 /* overwrite the staged Robot::v_ (v_prev) used by the next lmh_eval_host call: HOST [B][30] */
 int lmh_set_prev_velocity_host(lmh_handle *h, const double *v);
+/* hipStreamSynchronize(stream), then LMH_ERR_UNFINISHED if a completed lmh_rollout of this handle reported an incomplete launch (see there) */
 int lmh_synchronize(lmh_handle *h, void *stream);
 
 /* ---- end-of-run summary and on-disk records (the reference writes nothing but stdout,

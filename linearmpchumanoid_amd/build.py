@@ -18,38 +18,63 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+# Checker builds with a fixed meaning (never shipped; loaded with LMH_VARIANT=<name>); __graft_entry__.build() builds them so that they
+# travel to the GPU box, and the tests that use them assert lmh_debug_build_flags() so that a library built without its flag cannot pass.
+#   poison : every robot starts from an LDS image full of NaNs (tests/test_gpu_round3.py: no result depends on LDS nobody wrote)
+#   qfault : work-queue fault injection -- the pushes of every seventh robot are lost and the waits give up after 64 polls
+#            (tests/test_gpu_round4.py: an incomplete rollout is loud and leaves a clean launch slot)
+CHECKER_VARIANTS = {"poison": ["-DLMH_POISON"], "qfault": ["-DLMH_SPIN_LIMIT=64", "-DLMH_TEST_LOSE_PUSH=7"]}
+
+
+def _hipcc_cmd(so, extra):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # iterative-ilp machine scheduler: two waves per SIMD is all the rollout kernel's 248 VGPRs / 40 KB of LDS allow, so latency (not
+    # register pressure / occupancy) is what the scheduler should optimise; measured +19 % ticks/s over the default strategy (round 1).
+    sched = ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("LMH_SCHED", "iterative-ilp")]     # LMH_SCHED: experiments only
+    # machine LICM off: in the fused rollout loop it hoists ~100 literal constants (libm polynomial coefficients, LDS offsets) into VGPRs
+    # that stay live for the whole launch -> 256 VGPRs + SGPR / VGPR spills + scratch traffic that reaches HBM; without it the shipped
+    # kernel has 0 VGPR spills and 0 B of scratch (register budget).
+    if os.environ.get("LMH_KEEP_MACHINE_LICM") != "1":
+        sched += ["-mllvm", "-disable-machine-licm"]
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *sched, *extra,
+            *[os.path.join(CSRC, f) for f in SOURCES], "-o", so]
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     diag = ["-DLMH_SUBSTAMPS"] if DIAG else []                    # in-kernel sub-phase stamps (diagnostic build)
-    diag += VARIANT.split(":")[1:]
-    # iterative-ilp machine scheduler: the kernels run one wave per SIMD, so latency (not register pressure /
-    # occupancy) is what the scheduler should optimise; measured +19 % ticks/s over the default strategy.
-    sched = ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("LMH_SCHED", "iterative-ilp")]     # LMH_SCHED: experiments only
-    # machine LICM off: in the fused rollout loop it hoists ~100 literal constants (libm polynomial coefficients, LDS offsets) into VGPRs
-    # that stay live for the whole launch -> 256 VGPRs + scratch spills; without it the kernel needs 178 VGPRs and no scratch.
-    if os.environ.get("LMH_KEEP_MACHINE_LICM") != "1":
-        sched += ["-mllvm", "-disable-machine-licm"]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *sched, *diag,
-           *[os.path.join(CSRC, f) for f in SOURCES], "-o", SO]
+    name = VARIANT.split(":")[0]
+    diag += VARIANT.split(":")[1:] or CHECKER_VARIANTS.get(name, [])      # LMH_VARIANT=poison alone means the checker build, flag included
+    cmd = _hipcc_cmd(SO, diag)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return SO
 
 
-def build_variant(name, flags, force=False, verbose=False):
-    """Experiment / checker builds of the same sources into liblmh_hip_var_<name>.so (never the shipped library; loaded with
-    LMH_VARIANT=<name>).  `poison` (-DLMH_POISON: every robot starts from an LDS image full of NaNs) is built by
-    __graft_entry__.build() and used by tests/test_gpu_round3.py to prove that no result depends on LDS nobody wrote."""
-    so = os.path.join(_HERE, "liblmh_hip_var_%s.so" % name)
+def variant_path(name):
+    return os.path.join(_HERE, "liblmh_hip_var_%s.so" % name)
+
+
+def variant_cmd(name, flags=None):
+    """(path, hipcc command) of an experiment / checker build; flags default to CHECKER_VARIANTS[name]."""
+    flags = CHECKER_VARIANTS[name] if flags is None else flags
+    return variant_path(name), _hipcc_cmd(variant_path(name), list(flags))
+
+
+def variant_is_fresh(name):
+    so = variant_path(name)
     srcs = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    if not force and os.path.exists(so) and all(os.path.getmtime(f) <= os.path.getmtime(so) for f in srcs):
-        return so
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-           "-mllvm", "-disable-machine-licm", *flags, *[os.path.join(CSRC, f) for f in SOURCES], "-o", so]
+    return os.path.exists(so) and all(os.path.getmtime(f) <= os.path.getmtime(so) for f in srcs)
+
+
+def build_variant(name, flags=None, force=False, verbose=False):
+    """Experiment / checker builds of the same sources into liblmh_hip_var_<name>.so (never the shipped library; loaded with
+    LMH_VARIANT=<name>).  The checker builds of CHECKER_VARIANTS are built by __graft_entry__.build()."""
+    if not force and variant_is_fresh(name):
+        return variant_path(name)
+    so, cmd = variant_cmd(name, flags)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

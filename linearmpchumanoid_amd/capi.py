@@ -24,6 +24,8 @@ FLAG_NONFINITE = 2
 FLAG_ZMP_RANGE = 4
 FLAG_NOT_SPD = 8
 FLAG_QP_FP64_ROUTE = 16
+FLAG_UNFINISHED = 32          # lmh_rollout: the robot did not get all its ticks (a wait of the kernel's work queue ran out)
+ERR_UNFINISHED = -5
 
 PHASE_DOUBLE, PHASE_RIGHT, PHASE_LEFT, PHASE_FLIGHT = 0, 1, 2, 3
 PRECISION_FP64, PRECISION_MIXED, PRECISION_FP32 = 0, 1, 2   # lmh_config.precision (include/lmh.h)
@@ -116,9 +118,11 @@ def lib():
 
 
 class LmhError(RuntimeError):
-    pass
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
 
 
 def check(rc):
     if rc != 0:
-        raise LmhError(f"lmh error {rc}: {lib().lmh_last_error().decode()}")
+        raise LmhError(f"lmh error {rc}: {lib().lmh_last_error().decode()}", rc)

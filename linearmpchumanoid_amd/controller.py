@@ -217,6 +217,11 @@ class BatchedController:
                                      None if lg is None else _dev_ptr(lg), int(n_ticks), self._stream()))
         return out, status, lg
 
+    def synchronize(self):
+        """lmh_synchronize on the current stream: waits for it, and raises LmhError (code ERR_UNFINISHED) if a completed rollout of this
+        handle left robots part-way (they carry FLAG_UNFINISHED in their status records)."""
+        check(capi.lib().lmh_synchronize(self._h, self._stream()))
+
     def ik(self, q, com_target=(-0.02, 0.0, 0.26), rf=(0, -0.05, 0, 0, 0, 0), lf=(0, 0.05, 0, 0, 0, 0)):
         """Kinematics::desiredOperationalState + compute (invKinematics.cpp:11-52); q [B,30] device tensor, in place."""
         iters = torch.zeros((self.B,), dtype=torch.int32, device=self.device)

@@ -51,6 +51,7 @@ struct lmh_handle {
         hipEvent_t done = nullptr;    // recorded behind the last launch that used this slot
         LmhDevParams P_dev;           // what d_P currently holds
         bool valid = false, used = false;
+        bool checked = true;          // the error word of the last launch on this slot (d_ticket[3]) has been read
     } slot[kSlots];
     unsigned next_slot = 0;
 };
@@ -503,21 +504,41 @@ extern "C" int lmh_eval_debug(lmh_handle *h, double *d_state, double *d_out, int
     return LMH_OK;
 }
 
+// The error word of a COMPLETED launch on this slot (d_ticket[3], lmh_rollout_kernel): read once, cleared, reported.  The kernel has already
+// flagged the robots concerned and put the slot's ring / progress words back to zero.
+static int slot_take_error(lmh_handle *h, lmh_handle::Slot &sl)
+{
+    if (sl.checked) return LMH_OK;
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, sl.d_ticket + 3, sizeof(int), hipMemcpyDeviceToHost));
+    sl.checked = true;
+    if (err == 0) return LMH_OK;
+    HIPCHK(hipMemset(sl.d_ticket + 3, 0, sizeof(int)));
+    (void)h;
+    return fail(LMH_ERR_UNFINISHED, "lmh_rollout: a wait of the kernel's work queue ran out (error word " + std::to_string(err) +
+                "); the robots that did not get all their ticks carry LMH_FLAG_UNFINISHED in their status records");
+}
+
 extern "C" int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_t *d_status, double *d_log, int n_ticks, void *stream)
 {
     int rc = ready(h); if (rc) return rc;
     if (!d_state || !d_out || !d_status || n_ticks < 0) return fail(LMH_ERR_BAD_ARG, "bad argument");
     if (n_ticks == 0) return LMH_OK;
     HIPCHK(hipSetDevice(h->device));
-    lmh_handle::Slot &sl = h->slot[h->next_slot++ % lmh_handle::kSlots];
+    lmh_handle::Slot &sl = h->slot[h->next_slot % lmh_handle::kSlots];
     if (!sl.d_P) {
         HIPCHK(hipMalloc(&sl.d_P, sizeof(LmhDevParams)));
-        const size_t tbytes = (4 + 2 * (size_t)h->P.n_instances) * sizeof(int);   // counters | ring of robots | ticks done per robot
+        const size_t tbytes = (4 + 2 * (size_t)h->P.n_instances) * sizeof(int);   // counters | error word | ring of robots | ticks done per robot
         HIPCHK(hipMalloc(&sl.d_ticket, tbytes));
-        HIPCHK(hipMemset(sl.d_ticket, 0, tbytes));
+        HIPCHK(hipMemsetAsync(sl.d_ticket, 0, tbytes, (hipStream_t)stream));     // stream-ordered in front of the first launch on the slot
         HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
-    if (sl.used) HIPCHK(hipEventSynchronize(sl.done));              // the launch that last used this slot (kSlots launches ago) has left it
+    if (sl.used) {
+        HIPCHK(hipEventSynchronize(sl.done));                       // the launch that last used this slot (kSlots launches ago) has left it
+        rc = slot_take_error(h, sl);                                // ... and if it was incomplete, this call reports it instead of launching
+        if (rc) return rc;
+    }
+    h->next_slot++;
     if (!sl.valid || std::memcmp(&sl.P_dev, &h->P, sizeof(LmhDevParams)) != 0) {   // set-up calls changed the block since this slot was filled
         std::memcpy(&sl.P_dev, &h->P, sizeof(LmhDevParams));
         HIPCHK(hipMemcpyAsync(sl.d_P, &sl.P_dev, sizeof(LmhDevParams), hipMemcpyHostToDevice, (hipStream_t)stream));   // stream-ordered in front of the launch; the slot is idle
@@ -527,6 +548,7 @@ extern "C" int lmh_rollout(lmh_handle *h, double *d_state, double *d_out, int32_
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.done, (hipStream_t)stream));
     sl.used = true;
+    sl.checked = false;
     return LMH_OK;
 }
 
@@ -632,7 +654,10 @@ extern "C" int lmh_synchronize(lmh_handle *h, void *stream)
     if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    return LMH_OK;
+    int rc = LMH_OK;
+    for (auto &sl : h->slot)                                         // launches that have completed (on this stream or any other) and were not looked at yet
+        if (sl.used && !sl.checked && hipEventQuery(sl.done) == hipSuccess) { const int e = slot_take_error(h, sl); if (e) rc = e; }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------- end-of-run summary + on-disk records

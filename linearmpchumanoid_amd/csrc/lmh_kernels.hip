@@ -3374,8 +3374,18 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, d
 // One claim on the rollout's work queue (called by one thread of the workgroup): -1 when no unit is left, else the robot, with the ticks it has
 // behind it in *tick0.  Claims below n_inst are the robots' first chunks (no memory traffic); the others wait for their ring entry, which
 // is pushed by a workgroup that is RUNNING a chunk of that robot -- no workgroup owns a unit it has not claimed, so the queue drains with any
-// number of resident workgroups >= 1 (two launches sharing the chip, a debugger, a partitioned device).  The protocol is modelled under
-// random schedules in tests/test_host_logic.py::test_rollout_work_queue_protocol_drains_under_any_schedule.
+// number of resident workgroups >= 1 (two launches sharing the chip, a debugger, a partitioned device).  An entry is TAKEN by the exchange
+// itself (the value the exchange returns, not the value a load saw before it): two claimers one lap apart may poll the same slot, and only
+// one of them may leave with the robot.  The protocol is modelled under random schedules, the take split into its load and its exchange, in
+// tests/test_host_logic.py::test_rollout_work_queue_protocol_drains_under_any_schedule.
+// Both waits of the protocol are bounded (LMH_SPIN_LIMIT polls).  A wait that runs out sets the launch's error word ticket[3]; the robot
+// concerned stays part-way with a non-zero progress entry, and the last workgroup to leave turns every such entry into LMH_FLAG_UNFINISHED
+// in the robot's status record and puts the ring / progress words back to zero (lmh_rollout_kernel); the host reports the error word
+// (lmh_synchronize, or the next lmh_rollout on the slot: LMH_ERR_UNFINISHED).  The reference never fails silently either
+// (src/controller.cpp:448-476).
+#ifndef LMH_SPIN_LIMIT
+#define LMH_SPIN_LIMIT (1 << 26)
+#endif
 __device__ __forceinline__ int rollout_claim(int *ticket, int n_inst, long long n_units, int *tick0)
 {
     int *const ring = ticket + 4, *const prog = ticket + 4 + n_inst;
@@ -3385,13 +3395,14 @@ __device__ __forceinline__ int rollout_claim(int *ticket, int n_inst, long long 
     if (n < (long long)n_inst) return (int)n;
     int *slot = ring + (int)((n - n_inst) % n_inst);
     int v = 0;
-    for (int spin = 0; spin < (1 << 26); spin++) {                 // bounded: a lost push must not hang the chip (the robot then stays unfinished, visibly)
-        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v != 0) break;
+    for (int spin = 0; spin < LMH_SPIN_LIMIT; spin++) {            // bounded: a lost push must not hang the chip
+        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            v = atomicExch(slot, 0);                               // the take: whoever gets the non-zero value back owns the robot
+            if (v != 0) break;
+        }
         __builtin_amdgcn_s_sleep(16);
     }
-    if (v == 0) return -1;
-    atomicExch(slot, 0);
+    if (v == 0) { atomicOr(&ticket[3], 1); return -1; }            // loud: see above
     __threadfence();
     *tick0 = __hip_atomic_load(&prog[v - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v - 1;
@@ -3611,10 +3622,15 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             __threadfence();
             const int tpos = atomicAdd(&ticket[2], 1);             // the position is reserved; the entry goes in once the slot is empty: the taker of
             int *pslot = ring + tpos % n_inst;                     // the entry one lap earlier (a running workgroup, spinning on it) may not have been there yet
-            for (int spin = 0; spin < (1 << 26); spin++) {
-                if (atomicCAS(pslot, 0, inst + 1) == 0) break;
-                __builtin_amdgcn_s_sleep(16);
+            bool in = false;
+#ifdef LMH_TEST_LOSE_PUSH                                          // fault injection (checker build `qfault` only): the pusher of some robots never gets to its compare-and-swap
+            if (inst % LMH_TEST_LOSE_PUSH != 3)
+#endif
+            for (int spin = 0; spin < LMH_SPIN_LIMIT && !in; spin++) {
+                in = atomicCAS(pslot, 0, inst + 1) == 0;
+                if (!in) __builtin_amdgcn_s_sleep(16);
             }
+            if (!in) atomicOr(&ticket[3], 2);                      // the robot stays out of the queue: prog[inst] != 0 marks it (flagged by the last workgroup)
         } else prog[inst] = 0;
         const int next = rollout_claim(ticket, n_inst, n_units, &next0);
         s_next = next; s_tick0 = next0;
@@ -3624,10 +3640,30 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     tick0 = __builtin_amdgcn_readfirstlane(s_tick0);
     __threadfence();                                               // acquire: this CU's vector cache may hold the record as it was chunks ago
     }                                                              // next work unit of this workgroup (the next write of s_next is many barriers away)
-    if (threadIdx.x == 0) {                                        // every claim of this workgroup precedes this increment: the last one to leave resets the slot
+    __syncthreads();                                               // every wave has read the last claim's s_next
+    if (threadIdx.x == 0) {                                        // every claim and push of this workgroup precedes this increment: the last one to leave resets the slot
         __threadfence();
-        if (atomicAdd(&ticket[1], 1) == (int)gridDim.x - 1) { ticket[0] = 0; ticket[1] = 0; ticket[2] = 0; __threadfence(); }
+        const bool last = atomicAdd(&ticket[1], 1) == (int)gridDim.x - 1;
+        s_next = !last ? 0 : (__hip_atomic_load(&ticket[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 2 : 1;
     }
+    __syncthreads();
+    const int leave = s_next;                                      // 0: others are still at work | 1: last, clean launch | 2: last, a wait ran out
+    if (leave == 2) {
+        // nobody runs a robot any more: a non-zero progress entry is a robot that never got its remaining chunks.  It is flagged, and the
+        // ring / progress words go back to zero so that the next launch on this slot starts from the state it expects; ticket[3] is left
+        // for the host (lmh_capi.hip reads and clears it).
+        __threadfence();
+        for (int i = (int)threadIdx.x; i < n_inst; i += (int)blockDim.x) {
+            if (__hip_atomic_load(&prog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                atomicOr(&status[LMH_STATUS_STRIDE * i + 2], LMH_FLAG_UNFINISHED);
+                prog[i] = 0;
+            }
+            ring[i] = 0;
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    if (leave != 0 && threadIdx.x == 0) { ticket[0] = 0; ticket[1] = 0; ticket[2] = 0; __threadfence(); }
 }
 
 // Robot::Robot model preparation (Robot.cpp:14-22) + Dynamics::spatialInertiaMatrix pieces
@@ -4054,6 +4090,30 @@ extern "C" int lmh_debug_rollout_occupancy(int *groups_per_cu, int *num_regs, in
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lmh_rollout_kernel<double, false>, LMH_ROLLOUT_THREADS, 0) != hipSuccess) return -2;
     *groups_per_cu = nb; *num_regs = at.numRegs; *static_lds_bytes = (int)at.sharedSizeBytes;
     return 0;
+}
+// Diagnostic: which experiment switches THIS library was compiled with (bit 0 LMH_POISON, bit 1 LMH_SUBSTAMPS, bit 2 a non-default
+// LMH_SPIN_LIMIT, bit 3 LMH_NUM_VGPR, bit 4 LMH_LDS_PROBE_DOUBLES, bit 5 LMH_TEST_LOSE_PUSH); the checker tests assert it, so that a variant library built without
+// its flag cannot pass them vacuously.  Not part of the C ABI of include/lmh.h.
+extern "C" int lmh_debug_build_flags(void)
+{
+    int f = 0;
+#ifdef LMH_POISON
+    f |= 1;
+#endif
+#ifdef LMH_SUBSTAMPS
+    f |= 2;
+#endif
+    if (LMH_SPIN_LIMIT != (1 << 26)) f |= 4;
+#ifdef LMH_NUM_VGPR
+    f |= 8;
+#endif
+#ifdef LMH_LDS_PROBE_DOUBLES
+    f |= 16;
+#endif
+#ifdef LMH_TEST_LOSE_PUSH
+    f |= 32;
+#endif
+    return f;
 }
 // d_ticket: zero-initialised device memory owned by this launch until it completes (work-unit counters, ring, progress: see the kernel)
 extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_P, int *d_ticket, double *state, double *out, int32_t *status, double *log, int n_ticks, hipStream_t s)

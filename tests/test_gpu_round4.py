@@ -1,0 +1,116 @@
+"""GPU tests added in round 4: an incomplete rollout is loud (bounded waits of the kernel's work queue, LMH_FLAG_UNFINISHED,
+LMH_ERR_UNFINISHED, clean launch slot), BASELINE config 2 at its full push amplitude against the oracle on robots that fall, the
+evaluation-API lines of bench.py.  Same rules as the other GPU files: HIP path through the C ABI, the CPU oracle is the checker.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import WEIGHT, close, perturbed_velocities, vec_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DT = 1e-3
+
+
+def _run_probe(code, variant, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("LMH_VARIANT", "LMH_DIAG")}
+    if variant:
+        env["LMH_VARIANT"] = variant
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+# ------------------------------------------------------------------------------- an incomplete rollout is loud
+_QFAULT_PROBE = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+from linearmpchumanoid_amd import capi
+from linearmpchumanoid_amd.controller import BatchedController, default_config
+from helpers import perturbed_velocities
+ik = json.load(open("tests/golden/ik_posture.json"))
+B, NT = 96, 620                                    # 620 ticks = chunks of 250 + 250 + 120: every robot passes through the ring queue twice
+capi.lib().lmh_debug_build_flags.restype = int
+ctl = BatchedController(B, default_config(dt=1e-3, time_horizon=0.32 + 1e-9, z_com=ik["z_com"], mpc_dt=1e-2, warm_start=1))
+ctl.gen_walk(2.0, num_steps=3, time_per_step=0.3, ds_time=0.1, step_height=0.02, settle_time=0.05)
+ctl.set_xscale(np.linspace(0.02, 0.05, B))
+v0 = perturbed_velocities(B) * 0.3
+res = {"build_flags": capi.lib().lmh_debug_build_flags()}
+st = ctl.new_state(np.array(ik["q"]), v0, t=0.0)
+out, status, _ = ctl.rollout(st, NT)
+codes = []
+for _ in range(2):                                  # the error is reported once
+    try:
+        ctl.synchronize(); codes.append(0)
+    except capi.LmhError as e:
+        codes.append(e.code)
+s = status.cpu().numpy(); t = st[:, 90].cpu().numpy()
+res.update(sync_codes=codes, flags=s[:, 2].tolist(), ticks=[int(round(x / 1e-3)) for x in t])
+h1 = hashlib.sha256()
+for a in (out, status, st):
+    h1.update(a.cpu().numpy().tobytes())
+res["first_sha"] = h1.hexdigest()
+# the following launches on the SAME handle: single chunks (no ring traffic, so the fault injection has nothing to act on), enough of them to
+# come back to the launch slot the incomplete launch used (8 slots per handle)
+h = hashlib.sha256()
+st2 = ctl.new_state(np.array(ik["q"]), v0, t=0.0)
+for i in range(9):
+    out2, status2, log2 = ctl.rollout(st2, 60, log=True)
+    ctl.synchronize()
+    for a in (out2, status2, log2, st2):
+        h.update(a.cpu().numpy().tobytes())
+res["next_sha"] = h.hexdigest()
+res["next_flags"] = int((status2.cpu().numpy()[:, 2] != 0).sum())
+print(json.dumps(res))
+"""
+
+
+def test_incomplete_rollout_is_loud_and_leaves_a_clean_slot():
+    """The waits of the rollout kernel's work queue are bounded; when one runs out nothing may fail silently (the reference prints and
+    aborts, src/controller.cpp:448-476).  Checker build `qfault` (-DLMH_SPIN_LIMIT=64 -DLMH_TEST_LOSE_PUSH=7, build.CHECKER_VARIANTS):
+    the ring entry of every robot with index = 3 mod 7 is never pushed, and a claim gives up after 64 polls.  On a three-chunk launch of
+    96 robots: (i) every robot is either complete (620 ticks, no UNFINISHED flag) or carries LMH_FLAG_UNFINISHED with a whole number of
+    chunks behind it -- the robots whose push was lost among them; (ii) lmh_synchronize reports LMH_ERR_UNFINISHED, once; (iii) nine
+    following launches on the same handle (they come back to the slot of the incomplete one) are flag-free and BIT-IDENTICAL to the same
+    launches of the shipped library, whose first launch is complete and reports nothing."""
+    from linearmpchumanoid_amd import build as hipbuild
+    from linearmpchumanoid_amd import capi
+    hipbuild.build_variant("qfault")
+    good = _run_probe(_QFAULT_PROBE, "")
+    bad = _run_probe(_QFAULT_PROBE, "qfault")
+    assert good["build_flags"] == 0 and bad["build_flags"] == 4 | 32, (good["build_flags"], bad["build_flags"])
+    assert good["sync_codes"] == [0, 0] and all(f == 0 for f in good["flags"]) and all(t == 620 for t in good["ticks"])
+    assert bad["sync_codes"] == [capi.ERR_UNFINISHED, 0], bad["sync_codes"]
+    lost = [i for i in range(96) if i % 7 == 3]
+    n_done = 0
+    for i, (f, t) in enumerate(zip(bad["flags"], bad["ticks"])):
+        if f & capi.FLAG_UNFINISHED:
+            assert t in (250, 500), (i, t)                       # part-way: the record of the last chunk it completed
+        else:
+            assert t == 620 and f == 0, (i, f, t)
+            n_done += 1
+    assert all(bad["flags"][i] & capi.FLAG_UNFINISHED for i in lost)
+    assert n_done >= 48, n_done                                    # the queue kept working for the others
+    assert bad["next_flags"] == 0 and good["next_flags"] == 0
+    assert bad["next_sha"] == good["next_sha"]
+
+
+def test_poison_build_really_is_the_poison_build():
+    """Positive control of test_results_do_not_depend_on_uninitialised_lds: the library LMH_VARIANT=poison loads was compiled
+    with -DLMH_POISON (lmh_debug_build_flags bit 0), the shipped one was not."""
+    code = ("import json, os, sys; sys.path.insert(0, os.getcwd())\n"
+            "from linearmpchumanoid_amd import capi\n"
+            "L = capi.lib(); L.lmh_debug_build_flags.restype = int\n"
+            "print(json.dumps({'flags': L.lmh_debug_build_flags(), 'so': capi.SO_PATH}))\n")
+    from linearmpchumanoid_amd import build as hipbuild
+    hipbuild.build_variant("poison")
+    a, b = _run_probe(code, ""), _run_probe(code, "poison")
+    assert a["flags"] == 0 and a["so"].endswith("liblmh_hip.so")
+    assert b["flags"] == 1 and b["so"].endswith("liblmh_hip_var_poison.so")

@@ -1,6 +1,7 @@
 """CPU tests of host logic: reference generators, sharding and the summary gather (gloo, world 2)."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -9,6 +10,8 @@ import torch.multiprocessing as mp
 
 from linearmpchumanoid_amd import sharding, trajectories
 from oracle.pyoracle import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_stance_zmp_matches_reference_rule():
@@ -79,6 +82,34 @@ def test_summary_gather_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_summary_gather_world8_gloo_at_config4_size():
+    """BASELINE configs[3] / [4] as the driver's 8-GPU run shards them (no multi-GPU node was available to any
+    session): 8 ranks over gloo, 32 768 + 5 summary rows so that the shards are uneven (ranks 0..4 own 4097 rows, 5..7 own 4096) --
+    the gathered table equals the single-process summary row for row: order and count exact."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    total = 32768 + 5
+    assert [sharding.shard_range(total, 8, r)[1] for r in range(8)] == [4097] * 5 + [4096] * 3
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, total, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_bench_refuses_a_local_rank_without_a_device():
+    """bench.py under a launcher whose LOCAL_RANK has no GPU behind it (a node with fewer cards than ranks) says so in one line instead
+    of failing inside torch.cuda.set_device / the process group."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="11", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "LOCAL_RANK=11" in r.stderr and "visible" in r.stderr, r.stderr[-500:]
 
 
 def test_summary_fields():
@@ -160,7 +191,9 @@ def test_bench_defaults_name_the_largest_single_gpu_config():
     assert (c2.ticks, c2.horizon, c2.push) == (10, 16, 1.0) and c2.reset_every * c2.ticks <= 230
     txt = b.WORKLOAD_TEXT[3].format(B=4096, dt=1e-3, N=32, md=1e-2, push=1.0, st=0.5)
     assert "4096" in txt and "walking" in txt and "N=32" in txt and "mpc_dt=0.01" in txt
-    assert b.HARD_FLAGS == 15
+    assert b.HARD_FLAGS == 15 | 32                                  # MAXITER | NONFINITE | ZMP_RANGE | NOT_SPD | UNFINISHED
+    e = b.parse(["--mode", "eval"])
+    assert (e.config, e.instances, e.steps, e.warmup) == (3, 4096, 200, 20) and (d.steps, d.warmup) == (20, 5) and (a2.steps, a2.warmup) == (8, 2)
 
 
 def test_bench_gpus_flag_launches_ranks_and_propagates_failure():
@@ -236,57 +269,131 @@ def test_create_rejects_values_the_kernels_would_divide_by(hip_lib):
         hip_lib.lmh_destroy(h)
 
 
-def test_rollout_work_queue_protocol_drains_under_any_schedule():
-    """Model of the rollout kernel's work queue (lmh_kernels.hip: rollout_claim + the push at the end of a chunk), run under random
-    interleavings with FEWER runners than workgroups of the grid resident at a time: every (robot, chunk) unit is executed exactly once
-    and in order per robot, no runner waits for ever, and the counters / ring are back at zero.  The invariant the kernel relies on: a
-    claim beyond the robots' first chunks waits for a ring entry that only a RUNNING workgroup can push."""
-    import random
-    for seed, (n_inst, n_chunks, grid, resident) in enumerate([(7, 3, 4, 2), (16, 5, 8, 8), (5, 1, 5, 3), (9, 4, 12, 1), (32, 6, 8, 5), (3, 9, 6, 4)] * 8):
-        rng = random.Random(seed)
-        head = tail = 0
-        ring = [0] * n_inst
-        prog = [0] * n_inst
-        done = [[] for _ in range(n_inst)]
-        n_units = n_inst * n_chunks
-        # a workgroup: state machine 'claim' -> ('wait', slot) -> ('run', robot, chunk) -> ('push', slot, robot) -> 'claim' ... -> 'gone'
-        wgs = ["new"] * grid
-        running = set()
-        steps = 0
-        while any(w != "gone" for w in wgs):
-            steps += 1
-            assert steps < 200000, "the queue does not drain"
-            # the hardware keeps at most `resident` workgroups on the chip; one that has started stays until it leaves
-            cand = [i for i, w in enumerate(wgs) if w != "gone" and (i in running or len(running) < resident)]
-            i = rng.choice(cand)
-            running.add(i)
-            w = wgs[i]
-            if w == "new" or w == "claim":
-                n = head; head += 1
-                if n >= n_units:
-                    wgs[i] = "gone"; running.discard(i)
-                elif n < n_inst:
-                    wgs[i] = ("run", n, 0)
-                else:
-                    wgs[i] = ("wait", (n - n_inst) % n_inst)
-            elif w[0] == "push":                                   # (a slow taker of the entry one lap earlier may still hold the slot)
-                if ring[w[1]] == 0:
-                    ring[w[1]] = w[2] + 1
-                    wgs[i] = "claim"
-            elif w[0] == "wait":
-                v = ring[w[1]]
-                if v:
-                    ring[w[1]] = 0
-                    wgs[i] = ("run", v - 1, prog[v - 1])
+def _queue_model(rng, n_inst, n_chunks, grid, resident, spin_limit=None, atomic_take=True):
+    """One run of the model of the rollout kernel's work queue (lmh_kernels.hip: rollout_claim, the push at the end of a chunk, the last
+    workgroup's clean-up) under a random interleaving.  The take of a ring entry is TWO steps, as on the device: a load that sees a
+    non-zero slot, then an exchange whose RESULT decides (atomic_take=False models the round-3 kernel, which trusted the load).
+    spin_limit: polls after which a wait gives up (None = never).  Returns what the launch leaves behind."""
+    head = tail = left = err = 0
+    ring = [0] * n_inst
+    prog = [0] * n_inst
+    done = [[] for _ in range(n_inst)]
+    flagged = set()
+    n_units = n_inst * n_chunks
+    # a workgroup: 'claim' -> ('wait', slot, polls) -> ('take', slot, seen, polls) -> ('run', robot, chunk) -> ('push', slot, robot, polls) -> 'claim' ... -> 'gone'
+    wgs = ["new"] * grid
+    running = set()
+    steps = 0
+    while any(w != "gone" for w in wgs):
+        steps += 1
+        assert steps < 400000, "the queue does not drain"
+        # the hardware keeps at most `resident` workgroups on the chip; one that has started stays until it leaves
+        cand = [i for i, w in enumerate(wgs) if w != "gone" and (i in running or len(running) < resident)]
+        i = rng.choice(cand)
+        running.add(i)
+        w = wgs[i]
+
+        def leave():
+            nonlocal left, head, tail
+            wgs[i] = "gone"; running.discard(i)
+            left += 1
+            if left == grid:                                   # the last workgroup to leave resets the slot
+                if err:
+                    for r in range(n_inst):
+                        if prog[r]:
+                            flagged.add(r); prog[r] = 0
+                        ring[r] = 0
+                head = tail = left = 0
+
+        if w == "new" or w == "claim":
+            n = head; head += 1
+            if n >= n_units:
+                leave()
+            elif n < n_inst:
+                wgs[i] = ("run", n, 0)
             else:
-                _, r, c = w
-                assert len(done[r]) == c                           # chunks of a robot run in order, one at a time
-                done[r].append(c)
-                if c + 1 < n_chunks:
-                    prog[r] = c + 1
-                    wgs[i] = ("push", tail % n_inst, r); tail += 1  # the position is reserved; the entry goes in once the slot is empty
-                else:
-                    prog[r] = 0
-                    wgs[i] = "claim"
-        assert all(d == list(range(n_chunks)) for d in done)
-        assert not any(ring) and not any(prog) and tail == n_inst * (n_chunks - 1) and head == n_units + grid
+                wgs[i] = ("wait", (n - n_inst) % n_inst, 0)
+        elif w[0] == "push":                                   # (a slow taker of the entry one lap earlier may still hold the slot)
+            if ring[w[1]] == 0:
+                ring[w[1]] = w[2] + 1
+                wgs[i] = "claim"
+            elif spin_limit is not None and w[3] + 1 >= spin_limit:
+                err |= 2; wgs[i] = "claim"                     # the robot stays out of the queue, prog[robot] != 0 marks it
+            else:
+                wgs[i] = ("push", w[1], w[2], w[3] + 1)
+        elif w[0] == "wait":                                   # the relaxed load
+            if ring[w[1]]:
+                wgs[i] = ("take", w[1], ring[w[1]], w[2])
+            elif spin_limit is not None and w[2] + 1 >= spin_limit:
+                err |= 1; leave()
+            else:
+                wgs[i] = ("wait", w[1], w[2] + 1)
+        elif w[0] == "take":                                   # the exchange
+            v = ring[w[1]]; ring[w[1]] = 0
+            if not atomic_take:
+                v = w[2]                                       # round 3: the value the load saw
+            if v:
+                wgs[i] = ("run", v - 1, prog[v - 1])
+            else:
+                wgs[i] = ("wait", w[1], w[3] + 1)              # somebody else got it: keep waiting for the next push to this slot
+        else:
+            _, r, c = w
+            done[r].append(c)
+            if c + 1 < n_chunks:
+                prog[r] = c + 1
+                wgs[i] = ("push", tail % n_inst, r, 0); tail += 1   # the position is reserved; the entry goes in once the slot is empty
+            else:
+                prog[r] = 0
+                wgs[i] = "claim"
+    return dict(done=done, ring=ring, prog=prog, head=head, tail=tail, left=left, err=err, flagged=flagged)
+
+
+QUEUE_CASES = [(7, 3, 4, 2), (16, 5, 8, 8), (5, 1, 5, 3), (9, 4, 12, 1), (32, 6, 8, 5), (3, 9, 6, 4), (9, 4, 9, 9), (4, 8, 4, 4), (6, 3, 6, 2)]
+
+
+def test_rollout_work_queue_protocol_drains_under_any_schedule():
+    """Model of the rollout kernel's work queue (_queue_model), run under random interleavings with FEWER runners than workgroups of
+    the grid resident at a time (and with grid == robots, where laps of the ring meet): every (robot, chunk) unit is executed exactly
+    once and in order per robot, no runner waits for ever, and the counters / ring are back at zero.  The invariants the kernel relies
+    on: a claim beyond the robots' first chunks waits for a ring entry that only a RUNNING workgroup can push, and an entry is taken by
+    the exchange's result."""
+    import random
+    for seed, case in enumerate(QUEUE_CASES * 12):
+        n_inst, n_chunks, grid, resident = case
+        r = _queue_model(random.Random(seed), *case)
+        assert all(d == list(range(n_chunks)) for d in r["done"]), case
+        assert not any(r["ring"]) and not any(r["prog"]) and r["err"] == 0 and not r["flagged"]
+        assert r["head"] == 0 and r["tail"] == 0 and r["left"] == 0
+
+
+def test_rollout_work_queue_model_sees_the_non_atomic_take():
+    """The same model with the round-3 take (load, then an unconditional exchange whose result is ignored) runs robots' chunks twice
+    under some schedules: the model is able to see the defect the advisor reported, i.e. the green test above means
+    something."""
+    import random
+    broken = 0
+    for seed in range(400):
+        r = _queue_model(random.Random(seed), 9, 4, 9, 9, atomic_take=False, spin_limit=50)
+        if any(d != list(range(4)) for d in r["done"]):
+            broken += 1
+    assert broken > 0
+
+
+def test_rollout_work_queue_timeouts_are_loud_and_leave_a_clean_slot():
+    """Bounded waits (LMH_SPIN_LIMIT): when a poll budget runs out the launch's error word is set, every robot is either complete --
+    all its chunks exactly once, in order -- or flagged by the last workgroup to leave (a flagged robot ran a prefix of its chunks),
+    nothing runs twice, and ring / progress / counters are back at zero for the next launch on the slot."""
+    import random
+    seen_err = seen_partial = 0
+    for seed in range(300):
+        case = QUEUE_CASES[seed % len(QUEUE_CASES)]
+        n_inst, n_chunks, grid, resident = case
+        r = _queue_model(random.Random(1000 + seed), *case, spin_limit=(seed % 4) + 1)
+        for rb, d in enumerate(r["done"]):
+            assert d == list(range(len(d))), (case, seed)                       # in order, never twice
+            assert len(d) == n_chunks or rb in r["flagged"], (case, seed)       # complete or flagged
+            assert not (len(d) == n_chunks and rb in r["flagged"])
+        assert bool(r["flagged"]) <= bool(r["err"])
+        assert not any(r["ring"]) and not any(r["prog"]) and r["head"] == 0 and r["tail"] == 0 and r["left"] == 0
+        seen_err += bool(r["err"]); seen_partial += bool(r["flagged"])
+    assert seen_err > 20 and seen_partial > 20
