@@ -1696,6 +1696,7 @@ __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, do
         refs_pd_feet(L, P, inst, t, k);
         WSYNC();
     } else if (wid == 1) {                                         // chain A
+        WSTAMP(66);
         refs_ag(L, mass, ang);
         WSYNC();
         refs_momentum(L, mass, ang);
@@ -1705,6 +1706,7 @@ __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, do
         refs_pd_momentum(L, P, mass, zcom);
         WSYNC();
     } else {                                                       // chain B
+        WSTAMP(67);
         refs_vfoot_pdjoints(L, P);
         WSYNC();
         refs_pd_feet(L, P, inst, t, k);
@@ -2873,6 +2875,7 @@ __device__ __forceinline__ int qp_setup(double *L, LmhCParams &P, int wid, doubl
 // support), prepared by the helper wave; scratch: the CRBA parking area.  Needs the support phase of THIS evaluation in L[P_RPH].
 __device__ __forceinline__ void kinv_prework(double *L, LmhCParams &P)
 {
+    WSTAMP(63);
     const int ph0 = __builtin_amdgcn_readfirstlane((int)L[P_RPH]);
     unsigned forced = 0u;
     if (ph0 == LMH_PHASE_LEFT || ph0 == LMH_PHASE_FLIGHT) forced |= 0x0000FFFFu;
@@ -3228,6 +3231,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
             phase_newton_euler<R>(L);
             if (plant) phase_newton_euler<R, true>(L);
             STAMP(4);
+            WSTAMP(64);
             phase_jacobian<R>(L);
         }
         else phase_crba<R>(L, ibsel);
@@ -3240,7 +3244,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     STAMP(6);
     const bool ang = (P.w_com_ang != 0.0) || (dbg != nullptr);     // angular-momentum rows: only when weighted (or dumped)
     flags |= phase_refs<NW>(L, P, inst, t, wid, k_out, &ph, ang);
-    if (NW == 2 && wid == 0 && P.w_com_ang == 0.0 && !QF32) qp_prefill15(L, P);      // ahead of the join: wave 1's chain is the longer one
+    if (NW == 2 && wid == 0 && P.w_com_ang == 0.0 && !QF32) { WSTAMP(68); qp_prefill15(L, P); }      // ahead of the join: wave 1's chain is the longer one
     WSTAMP(7);
     bsync<NW>();
     WSTAMP(8);
@@ -3557,13 +3561,17 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             // references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick); then, while wave 0 runs the
             // cone solve and the recovery, its forward kinematics.  The world transforms land in S0 + [0, 378), which nothing touches until the next evaluation's phase_com_x.
             auto window = [&](int part) {
-                if (part == 0) rk4_stage<1>(L, stage, lane, dt, xd4, x, ksum, xs);     // in the helper's slack inside the QP set-up
+                if (part == 0) { WSTAMP(60); rk4_stage<1>(L, stage, lane, dt, xd4, x, ksum, xs); WSTAMP(69); }    // in the helper's slack inside the QP set-up
                 else {                                             // behind the join that frees the set-up scratch
+                    WSTAMP(61);
                     if (tn != ts) refs_prepare(L, *Pe, inst, tn);
+                    WSTAMP(62);
                     phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
+                    WSTAMP(70);
                 }
             };
             flags |= controller_eval<2, R, QF32, PIPE, decltype(window)>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3, window);
+            WSTAMP(71);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
                 const double xprev = xs;
@@ -3572,6 +3580,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
                 WSYNC();
                 if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xprev;
             }
+            WSTAMP(72);
         }
         if (log) {                                                  // each wave logs what it produced: wave 1 the torques, wave 0 the wrench
             double *lg = log + ((size_t)(tick0 + tick) * P.n_instances + inst) * 36;
@@ -3901,11 +3910,13 @@ __global__ void __launch_bounds__(64) lmh_ik_kernel(LmhDevParams P_arg, double *
     if (lane == 0 && iters_out) iters_out[inst] = iter;
 }
 
+#ifndef LMH_ROLLOUT_ONLY              // (scripts/isa_census.py compiles the fp64 rollout kernel alone)
 extern "C" void lmh_launch_ik(const LmhDevParams *P, double *q, const LmhIkTarget *target, int32_t *iters, hipStream_t s)
 {
     hipLaunchKernelGGL(lmh_ik_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, *target, iters);
 }
 
+#endif
 // End-of-run summary: 16 doubles per instance, the record the one RCCL gather moves.  One lane per robot; HBM-bound
 // (reads 66 + 36 doubles + 4 ints of each record once), 1.1 KB per robot.
 __global__ void __launch_bounds__(256) lmh_summary_kernel(int n, const double *state, const double *out, const int32_t *status, double *summary)
@@ -3945,11 +3956,13 @@ __global__ void __launch_bounds__(64) lmh_com_kernel(LmhDevParams P_arg, const d
     phase_com_x<1, double>(L, 0);
     if (LANE < 3) com[3 * (size_t)inst + LANE] = L[P_COM + LANE];
 }
+#ifndef LMH_ROLLOUT_ONLY
 extern "C" void lmh_launch_com(const LmhDevParams *P, const double *q, double *com, hipStream_t s)
 {
     hipLaunchKernelGGL(lmh_com_kernel, dim3(P->n_instances), dim3(64), 0, s, *P, q, com);
 }
 
+#endif
 // ============================================================================ reference generators on the device
 // The reference declares a walking generator (ZMP(Task, numSteps, timePerStep, simulationTime) / walkZMP, zmpGeneration.hpp:15-22) but never
 // defines it, and produces one polynomial set per step with footCoeffTrajectory / findPolyCoeff (footRefTrajectory.cpp:4-47,
@@ -4049,6 +4062,7 @@ extern "C" void lmh_launch_gen_jump(int n, double time_step, double stance_time,
     hipLaunchKernelGGL(lmh_gen_jump_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, time_step, stance_time, flight_time, zx, zy, phase);
 }
 
+#ifndef LMH_ROLLOUT_ONLY
 extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *out, int32_t *status, double *debug, hipStream_t s)
 {
     // precision 1 (LMH_PRECISION_MIXED): model terms in fp32 arithmetic, references and QP in fp64; the debug kernel is fp64 only
@@ -4061,6 +4075,7 @@ extern "C" void lmh_launch_eval(const LmhDevParams *P, double *state, double *ou
     else if (P->precision == 1) hipLaunchKernelGGL((lmh_eval_kernel<false, float>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
     else hipLaunchKernelGGL((lmh_eval_kernel<false, double>), dim3(P->n_instances), dim3(LMH_ROLLOUT_THREADS), 0, s, *P, state, out, status, debug);
 }
+#endif
 // d_P: device copy of *P (the rollout kernel reads its parameters through a pointer, see lmh_rollout_kernel)
 // Workgroups the device holds at once: LDS admits four robots per CU (40 KB each of 160 KB).
 static int rollout_resident_groups()
@@ -4120,11 +4135,16 @@ extern "C" void lmh_launch_rollout(const LmhDevParams *P, const LmhDevParams *d_
 {
     const int slots = rollout_resident_groups();
     const dim3 grid((unsigned)((P->n_instances < slots) ? P->n_instances : slots));
+#ifndef LMH_ROLLOUT_ONLY
     if (P->precision == 2) hipLaunchKernelGGL((lmh_rollout_kernel<float, true>), grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, d_ticket, state, out, status, log, n_ticks);
     else if (P->precision == 1) hipLaunchKernelGGL(lmh_rollout_kernel<float>, grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, d_ticket, state, out, status, log, n_ticks);
-    else hipLaunchKernelGGL(lmh_rollout_kernel<double>, grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, d_ticket, state, out, status, log, n_ticks);
+    else
+#endif
+    hipLaunchKernelGGL(lmh_rollout_kernel<double>, grid, dim3(LMH_ROLLOUT_THREADS), 0, s, d_P, d_ticket, state, out, status, log, n_ticks);
 }
+#ifndef LMH_ROLLOUT_ONLY
 extern "C" void lmh_launch_model(const double *raw, double *model, int n_models, const double *lcoef, hipStream_t s)
 {
     hipLaunchKernelGGL(lmh_model_kernel, dim3(n_models), dim3(64), 0, s, raw, model, n_models, lcoef);
 }
+#endif

@@ -114,3 +114,47 @@ def test_poison_build_really_is_the_poison_build():
     a, b = _run_probe(code, ""), _run_probe(code, "poison")
     assert a["flags"] == 0 and a["so"].endswith("liblmh_hip.so")
     assert b["flags"] == 1 and b["so"].endswith("liblmh_hip_var_poison.so")
+
+
+# ------------------------------------------------------------------------------- config 2 at BASELINE's amplitude: parity of the failure
+def test_config2_full_amplitude_fallers_match_the_oracle_until_either_gives_up():
+    """BASELINE configs[1] as SURVEY 8d states it: pushes U(-0.3, 0.3) m/s (seed 20260001 + i).  A backward push beyond ~0.18 m/s puts the
+    capture point behind the heel: the robot falls whatever the torques do (test_config2_balancers_complete_2000_ticks_without_a_flag).
+    The first two such robots of the draw (v_x = -0.294, -0.298 m/s), tick by tick against the oracle from the same state
+    (profiles/r04_config2_fallers.txt is the full table): tau and f agree to 1e-6 -- measured <= 3e-10 -- over the first 800 ticks, through
+    joint velocities of 100 rad/s; from there the fall is a chaotic tumble (|v| > 200 rad/s, |tau| > 1e3 N m) in which round-off of either
+    side doubles every few ticks, and BOTH give up within ten ticks of each other: the launch in which the GPU raises
+    LMH_FLAG_NONFINITE / NOT_SPD / QP_MAXITER is the one that covers the tick at which the oracle's log stops being finite."""
+    from linearmpchumanoid_amd.controller import BatchedController, default_config, ik_start_posture
+    from oracle.pyoracle import Oracle
+    N, md, nt, chunk = 16, 2e-2, 1200, 10
+    th = N * md + 1e-9
+    q0, zcom = ik_start_posture(0)
+    v_full = perturbed_velocities(1024)
+    idx = [i for i in range(1024) if v_full[i, 0] < -0.22][:2]
+    assert idx == [16, 32]
+    ctl = BatchedController(2, default_config(dt=DT, time_horizon=th, z_com=zcom, mpc_dt=md, warm_start=1))
+    ctl.set_refs_stance(nt * DT + 1.0, 2)
+    st = ctl.new_state(q0, v_full[idx], t=0.0)
+    out, status = ctl.new_out(), ctl.new_status()
+    log = torch.zeros((chunk, 2, 36), dtype=torch.float64, device=ctl.device)
+    glog = np.zeros((nt, 2, 36)); gflag = np.zeros((nt // chunk, 2), dtype=np.int64)
+    for c in range(nt // chunk):
+        ctl.rollout(st, chunk, out, status, log)
+        torch.cuda.synchronize()
+        glog[c * chunk:(c + 1) * chunk] = log.cpu().numpy()
+        gflag[c] = status.cpu().numpy()[:, 2]
+    for j, i in enumerate(idx):
+        o = Oracle(sim_time=nt * DT + 1.0, dt=md, horizon_time=th, do_ik=True)
+        ref = o.rollout(np.concatenate([q0, v_full[i]]), 0.0, nt, dt=DT, log=True)["log"]
+        fin = np.isfinite(ref).all(axis=1)
+        assert not fin.all(), "the oracle's robot did not fall"
+        t_orc = int(np.argmin(fin))
+        fl = np.nonzero(gflag[:, j])[0]
+        assert len(fl), "the GPU's robot did not raise a flag"
+        t_gpu = int(fl[0]) * chunk
+        assert t_gpu - chunk <= t_orc < t_gpu + 2 * chunk, (i, t_gpu, t_orc)
+        assert t_orc > 900
+        for tk in range(0, 800):
+            assert close(glog[tk, j, :24], ref[tk, :24]) and close(glog[tk, j, 24:], ref[tk, 24:], scale=WEIGHT), (i, tk)
+        assert max(vec_err(glog[tk, j, :24], ref[tk, :24]) for tk in range(0, 800, 7)) < 1e-8
