@@ -2,7 +2,7 @@
 #pragma once
 #include <stdint.h>
 
-#define LMH_MODEL_STRIDE 400  // per model: 28 x 14 doubles (Ibar 9 | m*c 3 | m | pad) + [392] total mass
+#define LMH_MODEL_STRIDE 400  // per model: 28 x 14 doubles (Ibar 9 | m*c 3 | m | Robot::desiredPosture of coordinate i, the record's spare slot) + [392] total mass
 #define LMH_BODY_STRIDE 14
 #define LMH_SEG_STRIDE 52
 #define LMH_ROLLOUT_THREADS 128   // fused rollout: two waves per robot (lmh_kernels.hip, bsync)

@@ -323,6 +323,15 @@ __device__ __forceinline__ double fast_rcp(double d)
     return y;
 }
 
+// one Newton step: ~2 ulp.  For the multipliers of a Gauss-Jordan elimination that is as good as the exact quotient (the error is a 1e-16
+// relative perturbation of the row operation; the eliminated column is never read again), and it takes two instructions off the dependent
+// chain pivot -> reciprocal -> multiplier -> update of every pivot.
+__device__ __forceinline__ double fast_rcp1(double d)
+{
+    const double y = __builtin_amdgcn_rcp(d);
+    return fma(fma(-d, y, 1.0), y, y);
+}
+
 __device__ __forceinline__ double bcast_lane(double x, int l)     // l is a compile-time constant after unrolling
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
@@ -623,37 +632,46 @@ __device__ __forceinline__ void dpp_fmac_self(double (&a)[N], double m)         
         asm volatile("s_nop 1\n\t" LMH_FS(0, 1, 2) : "+v"(a[C0]) : "v"(m), "n"(J));
     }
 }
-// one pivot, then the next.  ROWS = number of 16-lane DPP rows that carry an independent system (1: lanes 0..15; 2: the two feet of
-// kinv_compute); `rowon` switches a whole system off (its pivots are replaced by 1).
-template <int J, int N, int M>
+// one pivot, then the next.  GUARD = true: `rowon` switches a whole 16-lane DPP row off (its pivots are replaced by 1) and a pivot that is
+// not above `dmin` is replaced by 1 and reported in `bad` (kinv_compute: two feet on two DPP rows, a rank-deficient K_f is an expected
+// outcome).  GUARD = false (gj_solve_regs): every DPP row carries a copy of the system, so the pivot a lane sees is always the true one --
+// no guard selects, no test per pivot: lane J keeps 1 / d_J, and the caller looks at the signs once at the end.
+template <int J, int N, int M, bool GUARD = true>
 __device__ __forceinline__ void gj16_step(double (&a)[N], double (&b)[M], unsigned live, int l16, bool rowon, double dmin, int &bad, double &myinv)
 {
     if constexpr (J < N) {
         if ((live >> J) & 1u) {                                   // wave-uniform
             double d = bcast16<J>(a[J]);
-            if (rowon && !(d > dmin)) bad = 1;
-            d = (rowon && d > dmin) ? d : 1.0;
-            const double invd = fast_rcp(d);
-            const double nf = (l16 == J) ? 0.0 : -(a[J] * invd);
-            if (l16 == J) myinv = invd;
+            if constexpr (GUARD) {
+                if (rowon && !(d > dmin)) bad = 1;
+                d = (rowon && d > dmin) ? d : 1.0;
+            }
+            const double invd = fast_rcp1(d);
+            const bool piv = l16 == J;
+            const double nf = piv ? 0.0 : -(a[J] * invd);
+            myinv = piv ? invd : myinv;
             dpp_fmac_self<J + 1, N - 1 - J, J>(a, nf);
             dpp_fmac_self<0, M, J>(b, nf);
         }
-        gj16_step<J + 1>(a, b, live, l16, rowon, dmin, bad, myinv);
+        gj16_step<J + 1, N, M, GUARD>(a, b, live, l16, rowon, dmin, bad, myinv);
     }
 }
-// On exit b[r] of lane i < N holds x_i.  Returns non-zero (wave-uniform) if a pivot was not positive.
+// Lane l holds row l & 15 of the system (rows >= N: any finite copy, e.g. row 0 -- they are eliminated like every other row and never read):
+// all four 16-lane DPP rows then run the same elimination.  On exit b[r] of lane i < N holds x_i.  Returns non-zero (wave-uniform) if a
+// pivot was not positive (d_i > 0 <=> 0 < 1 / d_i < inf on the lane that kept it; the caller flags LMH_FLAG_NOT_SPD, and the non-finite
+// values that follow a bad pivot are flagged LMH_FLAG_NONFINITE by the evaluation's own check).
 template <int N, int M>
 __device__ __forceinline__ int gj_solve_regs(double (&a)[N], double (&b)[M], unsigned live)
 {
     static_assert(N <= 16, "one DPP row");
-    const int lane = LANE;
+    const int l16 = LANE & 15;
     int bad = 0;
     double myinv = 0.0;
-    gj16_step<0>(a, b, live, lane, lane < 16, 0.0, bad, myinv);
+    gj16_step<0, N, M, false>(a, b, live, l16, true, 0.0, bad, myinv);
 #pragma unroll
     for (int r = 0; r < M; r++) b[r] *= myinv;
-    return (__ballot(bad != 0) != 0ull) ? 1 : 0;
+    const bool pivot_lane = ((live >> l16) & 1u) != 0u;            // (bits >= N of `live` are clear)
+    return (__ballot(pivot_lane && !(myinv > 0.0 && myinv <= 1.7976931348623157e308)) != 0ull) ? 1 : 0;
 }
 
 
@@ -829,6 +847,7 @@ __device__ __forceinline__ void bdot6(float &acc, float src, const float (&m)[6]
 // Exec-masked LDS stores (s_and_saveexec / ds_write / s_or) cost ~28 cycles each; a store whose address is switched to a dump slot for
 // the lanes that have nothing to write costs one v_cndmask more than a plain one.
 #define P_DUMP (P_TIME + 5)        // never read
+#define NE_DUMP (S0 + 840)         // 32 doubles nobody reads: between the Newton-Euler arrays and the X images (free during the kinematic / tree phases)
 
 // limb rows: frame of (row, depth d) = fb + d with fb = base of the limb; the right-arm row switches to the head frames at depth 5
 struct TreeRows {
@@ -870,68 +889,77 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
             }
         }
         cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
-        if (lane == 0) {
+        {   // one division sequence for the three components (lanes 0..2), not three on lane 0
             const R mass = L[P_MODEL + 392];
-            L[P_COM] = cx / mass; L[P_COM + 1] = cy / mass; L[P_COM + 2] = cz / mass;
+            const R num = (lane == 0) ? cx : (lane == 1) ? cy : cz;
+            L[(lane < 3) ? P_COM + lane : (int)P_DUMP] = num / mass;
         }
     }
     SUBSTAMP(2);
     WSTAMP(46);
-    const int f_lo = (NW == 2 && wid == 1) ? 14 : 1;               // first frame of the E, p loop
-    const int f_n = (NW == 1) ? 27 : (wid ? 14 : 13);
-    {   // frames 1..27: E = Rp' Ri, p = Rp' pi + (-Rp') pp.  Lane = (frame slot fr < 5, entry el < 12): everything derived from
-        // el is a per-lane constant, only the frame index moves from round to round (five frames per round)
-        const int fr = (lane < 60) ? lane / 12 : 0, el = lane % 12;
-        const bool isE = el < 9;
-        const int a = isE ? el / 3 : el - 9, col = isE ? el % 3 : 3;
-        // E[a][col] = A[col][a]: top-left and bottom-right blocks of the image; p -> A_XP
-        const int s1 = isE ? A_XF + 6 * col + a : A_XP + (el - 9), s2 = A_XF + 6 * (3 + col) + 3 + a, sstr = isE ? 36 : 3;
-        constexpr int ROUNDS = (NW == 1) ? 6 : 3;
+    // frames of this wave: NW = 2: wave 0 works on 1..14 (and frame 0 below), wave 1 on 14..27 -- frame 14 is done by both, from the same
+    // inputs with the same instructions, so the two stores carry the same bits; NW = 1: 1..27.  Seven frames per round,
+    // lane = (frame slot fr < 7, entry e9 = 3 a + col < 9); lane 63 repeats lane 62.  The same map serves E (this pass) and B (below), so
+    // everything derived from the lane is computed once, and from round to round only compile-time offsets move.
+    const int f_lo = (NW == 2 && wid == 1) ? 14 : 1;
+    constexpr int ROUNDS = (NW == 1) ? 4 : 2;
+    const unsigned ln = (unsigned)((lane < 62) ? lane : 62);
+    const int fr = (int)(__umul24(ln, 57u) >> 9), e9 = (int)ln - 9 * fr;             // ln / 9, ln % 9 (exact for ln < 64)
+    const int a = (int)(__umul24((unsigned)e9, 11u) >> 5), col = e9 - 3 * a;         // e9 / 3, e9 % 3 (exact for e9 < 9)
+    const int i0 = f_lo + fr;                                                        // frame of round 0
+    const unsigned rootm = 0x02108102u >> i0;                                        // bit 7 u: the frame of round u hangs off the base (Robot.cpp:165)
+    {   // E = Rp' Ri: E[a][col] = A[col][a] goes to the top-left and bottom-right blocks of the image (A_XF + 36 i + 6 col + a, + 21), and
+        // the lane also clears one entry of the image's zero block (+ 3): the QP phases reuse this scratch, so it is rewritten per evaluation
+        const LV<R> Ti0 = L + (A_T + (int)__umul24((unsigned)i0, 12u) + col), Tr = L + (A_T + a), Tq0 = Ti0 + (a - col - 12);
+        const LV<R> O0 = L + (A_XF + (int)__umul24((unsigned)i0, 36u) + 6 * col + a);
 #pragma unroll
         for (int u = 0; u < ROUNDS; u++) {
-            const int fo = 5 * u + fr;
-            const bool on = (lane < 60) && (fo < f_n);
-            const int i = f_lo + (on ? fo : 0);
-            const LV<R> Ti = L + A_T + 12 * i + col, Tp = L + A_T + 12 * f_parent(i);
-            const R t0 = Tp[a], t1 = Tp[4 + a], t2 = Tp[8 + a];
+            const bool guard = (NW == 1) && (1 + 7 * u + 6 > 27);  // the last round of the single-wave schedule runs past frame 27
+            const bool on = !guard || (fr < 27 - 7 * u);
+            const LV<R> Ti = Ti0 + 84 * u, Tp = ((rootm >> (7 * u)) & 1u) ? Tr : Tq0 + 84 * u;
+            const R val = (R)Tp[0] * (R)Ti[0] + (R)Tp[4] * (R)Ti[4] + (R)Tp[8] * (R)Ti[8];
+            if (!guard) { const LV<R> O = O0 + 252 * u; O[0] = val; O[21] = val; O[3] = 0.0; }
+            else { const LV<R> O = on ? O0 + 252 * u : L + (int)NE_DUMP; O[0] = val; O[21 * (int)on] = val; O[3] = 0.0; }
+        }
+    }
+    {   // p = Rp' (pi - pp) in the reference's association: lane = (frame slot < 21, component a3 < 3); lane 63 repeats lane 62
+        const int fr3 = (int)(__umul24(ln, 43u) >> 7), a3 = (int)ln - 3 * fr3;        // ln / 3, ln % 3 (exact for ln < 64)
+        const int j0 = f_lo + fr3;
+        constexpr int PR = (NW == 1) ? 2 : 1;
+#pragma unroll
+        for (int u = 0; u < PR; u++) {
+            const bool on = (NW == 2) ? (fr3 < 14) : (21 * u + fr3 < 27);
+            const int i = on ? j0 + 21 * u : 1;
+            const LV<R> Ti = L + (A_T + 12 * i + 3), Tp = L + (A_T + 12 * f_parent(i));
+            const R t0 = Tp[a3], t1 = Tp[4 + a3], t2 = Tp[8 + a3];
             const R v1 = t0 * Ti[0] + t1 * Ti[4] + t2 * Ti[8];
             const R v2 = (-t0) * Tp[3] + (-t1) * Tp[7] + (-t2) * Tp[11];
-            const R val = isE ? v1 : v1 + v2;
-            if (on) { L[s1 + sstr * i] = val; if (isE) L[s2 + 36 * i] = val; }
+            L[on ? A_XP + 3 * i + a3 : (int)NE_DUMP + 8] = v1 + v2;
         }
     }
     if (wid == 0 && lane < 12) {                                   // frame 0: E = R0, p = p0
         const LV<R> T0 = L + A_T;
         if (lane < 9) {
-            const int a = lane / 3, c = lane % 3;
-            const R v = T0[a * 4 + c];
-            L[A_XF + 6 * c + a] = v; L[A_XF + 6 * (3 + c) + 3 + a] = v;
+            const int a0 = lane / 3, c0 = lane % 3;
+            const R v = T0[a0 * 4 + c0];
+            L[A_XF + 6 * c0 + a0] = v; L[A_XF + 6 * (3 + c0) + 3 + a0] = v; L[A_XF + 6 * c0 + 3 + a0] = 0.0;
         } else L[A_XP + (lane - 9)] = T0[(lane - 9) * 4 + 3];
-    }
-    {   // the zero block of every image of this wave's frames (the QP phases reuse this scratch, so it is rewritten per evaluation)
-        const int z_lo = (NW == 2 && wid == 1) ? 14 : 0, z_n = (NW == 1) ? 28 : 14;
-        for (int e = lane; e < 9 * z_n; e += 64) {
-            const int f = z_lo + e / 9, rr = (e % 9) / 3, c = e % 3;
-            L[A_XF + 36 * f + 6 * rr + 3 + c] = 0.0;
-        }
     }
     WSYNC();
     SUBSTAMP(3);
     WSTAMP(47);
-    const int b_lo = (NW == 2 && wid == 1) ? 14 : 0, b_n = (NW == 1) ? 28 : 14;
-    {   // B = (-E') [p]x, entry (a, b) = sg1 E[r1][a] p[j1] + sg2 E[r2][a] p[j2]; lane = (frame slot < 7, entry < 9), seven frames per round
-        const int fr = (lane < 63) ? lane / 9 : 0, e9 = lane % 9, a = e9 / 3, bb = e9 % 3;
+    {   // B = (-E') [p]x, entry (a, b) = sg1 E[r1][a] p[j1] + sg2 E[r2][a] p[j2]; same lane map (a, bb = col); frames: wave 0 0..13,
+        // wave 1 14..27 (NW = 1: 0..27)
+        const int bb = col;
         const int r1 = (bb == 0) ? 1 : 0, j1 = (bb == 2) ? 1 : 2, r2 = (bb == 2) ? 1 : 2, j2 = (bb == 0) ? 1 : 0;
         const R sg1 = (bb == 1) ? (R)1 : (R)-1, sg2 = (bb == 1) ? (R)-1 : (R)1;
-        constexpr int ROUNDS = (NW == 1) ? 4 : 2;
+        const int ib = ((NW == 2 && wid == 1) ? 14 : 0) + fr;
+        const LV<R> X0 = L + (A_XF + (int)__umul24((unsigned)ib, 36u) + 6 * a), q0 = L + (A_XP + 3 * ib);    // E[row][a] = A[a][row]: contiguous in the row index
+        const LV<R> X1 = X0 + r1, X2 = X0 + r2, q1 = q0 + j1, q2 = q0 + j2, Ob = X0 + (18 + bb);
 #pragma unroll
         for (int u = 0; u < ROUNDS; u++) {
-            const int fo = 7 * u + fr;
-            const bool on = (lane < 63) && (fo < b_n);
-            const int i = b_lo + (on ? fo : 0);
-            const LV<R> X = L + A_XF + 36 * i + 6 * a, p = L + A_XP + 3 * i;      // E[row][a] = A[a][row]: contiguous in the row index
-            const R val = (sg1 * (R)X[r1]) * (R)p[j1] + (sg2 * (R)X[r2]) * (R)p[j2];
-            if (on) L[A_XF + 36 * i + 6 * (3 + a) + bb] = val;
+            const R val = (sg1 * (R)X1[252 * u]) * (R)q1[21 * u] + (sg2 * (R)X2[252 * u]) * (R)q2[21 * u];
+            Ob[252 * u] = val;
         }
     }
     WSYNC();
@@ -941,8 +969,8 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
         // persistent copies: T0, T7, T14, X0 = E0 (9) | p0 (3) | B0 (9)
         if (lane < 36) L[P_TB + lane] = L[A_T + 12 * ((lane < 12) ? 0 : (lane < 24) ? 7 : 14) + lane % 12];
         if (lane < 21) {
-            const int e = (lane < 9) ? lane : (lane < 12) ? 0 : lane - 12, a = e / 3, b = e % 3;
-            L[P_X0 + lane] = (lane < 9) ? L[A_XF + 6 * b + a] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XF + 6 * (3 + a) + b];
+            const int e = (lane < 9) ? lane : (lane < 12) ? 0 : lane - 12, a0 = e / 3, b0 = e % 3;
+            L[P_X0 + lane] = (lane < 9) ? L[A_XF + 6 * b0 + a0] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XF + 6 * (3 + a0) + b0];
         }
         // base-frame reordered velocities, stale (Robot::v_) and fresh: swapBaseVelocityAndRefToWorldFrame
         if (lane < 60) {
@@ -959,6 +987,26 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
     WSYNC();
 }
 
+// ---- duplicate-lane form of the row layout (Newton-Euler, feet Jacobian).  Every lane of a 16-lane row works: lanes 6..11 repeat
+// components 0..5, lanes 12..15 components 0, 1, 2, 5.  A DPP row_newbcast:k reads lanes 0..5 of the own row, so a repeating lane computes
+// bit for bit what the lane it repeats computes (the +-1 lane shifts of the velocity cross term meet the right neighbours under this map:
+// component 0 needs 1, 1 needs 0, 3 needs 4, 4 needs 3; 2 and 5 need none), and its stores hit the same address with the same bits.  What
+// this buys: no "idle lane" store switches at all -- every store address is (per-lane base, computed once per sweep) + (compile-time offset
+// of the level).  The left-arm row repeats the right-arm row's head frames at depths 5, 6 in the same way.
+struct TreeDup { int rho, r, fb, fa, adj; bool arms; };
+__device__ __forceinline__ TreeDup tree_dup()
+{
+    TreeDup t;
+    const int lane = LANE, l16 = lane & 15;
+    t.rho = lane >> 4;
+    t.r = (int)((0x5210543210543210ull >> (4 * l16)) & 15ull);
+    t.arms = t.rho >= 2;
+    t.fb = 1 + 7 * t.rho - ((t.rho == 3) ? 2 : 0);               // 1, 8, 15, 20: depths 0..4
+    t.fa = t.arms ? 20 : t.fb;                                     // depths 5, 6: the head (25, 26) behind either arm
+    t.adj = t.arms ? 2 : t.rho;                                    // act(frame) = frame - adj on every limb (Robot.cpp:172)
+    return t;
+}
+
 // Dynamics::computeC (gravity / no gravity) + computeJpqpFrame(7),(14): forward and backward
 // Newton-Euler with qdd = 0 on the STALE velocity (Dynamics.cpp:29-60,124-200).
 // PLANT = true is the build-defined plant's own pass (lmh_config.plant): the same recursion on the CURRENT velocity (P_VHN), result
@@ -970,11 +1018,15 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
     const int lane = LANE;
     constexpr int VSRC = PLANT ? (int)P_VHN : (int)P_VHS;
     constexpr int CDST = PLANT ? (int)P_VHS : (int)P_C;
-    const TreeRows tr = tree_rows();
+    const TreeDup tr = tree_dup();
     const int r = tr.r;
+    // per-lane bases: frame of depth d = fb + d (d < 5) | fa + d (d = 5, 6)
+    const LV<R> Xrb = L + (A_XF + 36 * tr.fb + 6 * r), Xra = L + (A_XF + 36 * tr.fa + 6 * r);        // row r of X_f
+    const LV<R> Qb = L + (VSRC + 5 + tr.fb - tr.adj), Qa = L + (VSRC + 5 + tr.fa - tr.adj);          // joint rate of frame f
+    const LV<R> Vb = L + (A_VEL + 6 * tr.fb + r), Va = L + (A_VEL + 6 * tr.fa + r);                  // A_VEL | + 168 A_ACCG | + 336 A_ACC0
     // base: vel0 = vhat[0:6]; accg0 = X0 * [0 0 0 0 0 9.81]; acc00 = 0
     const R bv = L[VSRC + r], bg = (R)L[A_XF + 6 * r + 5] * (R)9.81;
-    if (lane < 6) { L[A_VEL + lane] = bv; L[A_ACCG + lane] = bg; L[A_ACC0 + lane] = 0.0; }
+    L[A_VEL + r] = bv; L[A_ACCG + r] = bg; L[A_ACC0 + r] = 0.0;
     {   // velocity and acceleration sweeps down the limbs, one frame per depth, recurrences in registers:
         // v_i = X_i v_p + S qd_i; a_i = X_i a_p + crm(v_i) S qd_i (with / without gravity in the base acceleration)
         const R s2 = (r == 2) ? (R)1 : (R)0;                       // S = e_z (angular): component 2
@@ -985,30 +1037,27 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
         R xs[7][6], qds[7];
 #pragma unroll
         for (int d = 0; d < 7; d++) {
-            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
-            const LV<R> X = L + A_XF + 36 * f + 6 * r;
+            const LV<R> X = (d < 5) ? Xrb + 36 * d : Xra + 36 * d;
 #pragma unroll
             for (int k = 0; k < 6; k++) xs[d][k] = X[k];
-            qds[d] = L[VSRC + 5 + f - tr.adj];
+            qds[d] = (d < 5) ? Qb[d] : Qa[d];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < 7; d++) {
-            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
             const R (&x)[6] = xs[d];
             R qd = qds[d];
-            if (d == 6) qd = (tr.rho < 2) ? (R)0 : qd;             // the soles carry no joint
-            if (d == 5) { pv = (tr.rho == 2) ? bv : pv; pg = (tr.rho == 2) ? bg : pg; p0 = (tr.rho == 2) ? (R)0 : p0; }   // the head starts from the base
+            if (d == 6) qd = tr.arms ? qd : (R)0;                  // the soles carry no joint
+            if (d == 5) { pv = tr.arms ? bv : pv; pg = tr.arms ? bg : pg; p0 = tr.arms ? (R)0 : p0; }   // the head starts from the base
             R v = s2 * qd;
             bdot6(v, pv, x);
             asm volatile("s_nop 1");                               // v feeds the lane shifts below
             const R cs = (ca * dpp_row<0x101>(v) + cb * dpp_row<0x111>(v)) * qd;      // row_shl:1 (lane + 1) | row_shr:1 (lane - 1)
             R ag = cs, a0 = cs;
             bdot6(ag, pg, x);
-            bdot6(a0, p0, x);
-            const bool on = tr.on6 && (d < 5 || tr.rho != 3);      // the left-arm row idles behind its five frames
-            const int fs = on ? 6 * f + r : (int)(P_DUMP - A_VEL); // idle lanes: dump slot (frame 27's entries of the three arrays are never read either)
-            L[A_VEL + fs] = v; L[on ? A_ACCG + 6 * f + r : (int)P_DUMP] = ag; L[on ? A_ACC0 + 6 * f + r : (int)P_DUMP] = a0;
+            if (d > 0) bdot6(a0, p0, x);                           // (the base's gravity-free acceleration is zero)
+            const LV<R> O = (d < 5) ? Vb + 6 * d : Va + 6 * d;
+            O[0] = v; O[168] = ag; O[336] = a0;
             pv = v; pg = ag; p0 = a0;
         }
     }
@@ -1050,36 +1099,48 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
     SUBSTAMP(7);
     WSTAMP(50);
     {   // backward sweep up the limbs: fs_i = f_i + X_c' fs_c (child c), C[joint of i] = fs_i[2]; the limb roots (and the head's) are parked
-        // for the base sum.  Depth 6 is the massless sole on the leg rows (skipped) and the head's leaf on the right-arm row.
-        R cg = 0, c0 = 0;
+        // for the base sum.  Depth 6 is the massless sole on the leg rows (no force: the legs start at depth 5) and the head's leaf on the
+        // arm rows.  The running sum of a level starts from the parent's own body force, so a level is the twelve DPP FMAs and nothing else.
+        const LV<R> Xcb = L + (A_XF + 36 * tr.fb + r), Xca = L + (A_XF + 36 * tr.fa + r);              // column r of X_f: stride 6
+        const LV<R> Fb = L + (A_FG + 6 * tr.fb + r), Fa = L + (A_FG + 6 * tr.fa + r);                  // A_FG | + 168 A_F0
+        // C[5 + act(frame)] = fs[2] (with gravity): the lanes that hold component 2 store, the others go to the dump; depth 6: arms only
+        const bool r2 = r == 2;
+        const LV<R> Cb = L + (r2 ? CDST + 5 + tr.fb - tr.adj : (int)NE_DUMP), Ca5 = L + (r2 ? CDST + 5 + tr.fa - tr.adj : (int)NE_DUMP);
+        const LV<R> Ca6 = L + ((r2 && tr.arms) ? CDST + 5 + tr.fa - tr.adj : (int)NE_DUMP);
+        const LV<R> Pk5 = L + (tr.arms ? A_VEL + 48 + r : (int)NE_DUMP + 8);                          // the head's root -> base slot 4 (arm rows)
         R ws[7][6], fgs[7], f0s[7];                                // all depths' operands up front (see the forward sweep)
 #pragma unroll
         for (int d = 6; d >= 0; d--) {
-            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
-            const LV<R> X = L + A_XF + 36 * f + r;                 // column r of X_f
+            const LV<R> X = (d < 5) ? Xcb + 36 * d : Xca + 36 * d;
 #pragma unroll
             for (int k = 0; k < 6; k++) ws[d][k] = X[6 * k];
-            fgs[d] = L[A_FG + 6 * f + r]; f0s[d] = L[A_F0 + 6 * f + r];
+            const LV<R> F = (d < 5) ? Fb + 6 * d : Fa + 6 * d;
+            fgs[d] = F[0]; f0s[d] = F[168];
         }
         __builtin_amdgcn_sched_barrier(0);
+        R fg = tr.arms ? fgs[6] : (R)0, f0 = tr.arms ? f0s[6] : (R)0;          // total force of the frame at depth 6
+        Ca6[6] = fg;
 #pragma unroll
         for (int d = 6; d >= 0; d--) {
-            const int f = ((d < 5) ? tr.fbB : tr.fbA) + d;
-            const bool active = (d < 5) || (d == 5 && tr.rho != 3) || (d == 6 && tr.rho == 2);
-            const bool root = (d == 0) || (d == 5 && tr.rho == 2);
-            const R fg = fgs[d] + cg, f0 = f0s[d] + c0;
-            L[(tr.on6 && active && (lane & 15) == 2) ? CDST + 5 + f - tr.adj : (int)P_DUMP] = fg;    // C[5 + act(frame)] (with gravity)
             const R (&w)[6] = ws[d];
-            R ng = 0, n0 = 0;
-            bdot6(ng, fg, w);
-            bdot6(n0, f0, w);
-            if (d == 0 || d == 5) {                                // A_VEL is dead after the body forces: slot = chain (RL, LL, RA, LA, head)
-                const int ch = (d == 5) ? 4 : tr.rho;
-                const bool pk = tr.on6 && active && root;
-                L[pk ? A_VEL + 12 * ch + r : (int)P_DUMP] = ng; L[pk ? A_VEL + 12 * ch + 6 + r : (int)P_DUMP] = n0;
+            if (d == 5) Ca5[5] = fg; else if (d < 5) Cb[d] = fg;
+            if (d == 0) {                                          // limb roots: X' fs parked for the base sum, slot = chain (RL, LL, RA, LA)
+                R ng = 0, n0 = 0;
+                bdot6(ng, fg, w);
+                bdot6(n0, f0, w);
+                L[A_VEL + 12 * tr.rho + r] = ng; L[A_VEL + 12 * tr.rho + 6 + r] = n0;         // A_VEL is dead after the body forces
+            } else if (d == 5) {                                   // arm rows: the head's root (parked, slot 4), the arm's tip starts afresh
+                R ng = tr.arms ? (R)0 : fgs[4], n0 = tr.arms ? (R)0 : f0s[4];
+                bdot6(ng, fg, w);
+                bdot6(n0, f0, w);
+                Pk5[0] = ng; Pk5[6] = n0;
+                fg = tr.arms ? fgs[4] : ng; f0 = tr.arms ? f0s[4] : n0;
+            } else {
+                R ng = fgs[d - 1], n0 = f0s[d - 1];
+                bdot6(ng, fg, w);
+                bdot6(n0, f0, w);
+                fg = ng; f0 = n0;
             }
-            const bool keep = active && !root;
-            cg = keep ? ng : (R)0; c0 = keep ? n0 : (R)0;
         }
     }
     WSYNC();
@@ -1256,23 +1317,42 @@ __constant__ double c_ib_sgn[36] = {1, 1, 1, 0, -1, 1, 1, 1, 1, 1, 0, -1, 1, 1, 
 // entry (i, j) of the 6 x 6 body inertia [Ibar, [h]x; -[h]x, m 1] (Dynamics.cpp:4-13) = sgn * record[idx]; per lane: tile t = 2 ta + tc holds
 // element (4 ta + rho, 4 tc + q), set s = iteration parity (the gather of set s is transposed when s ^ leg)
 struct IbSel { int i[2][4]; double s[2][4]; };
-__device__ __forceinline__ IbSel ib_select()
+// The gather table of a lane is a launch constant but 24 registers wide; the rollout keeps it PACKED in two registers across its tick loop
+// (six bits per (set, tile): record index 0..12 | sign as a two-bit two's-complement number) and unpacks it per evaluation with three
+// instructions per entry -- against sixteen constant-memory loads behind ~100 instructions of index arithmetic per evaluation before.
+struct IbPack { unsigned w[2]; };
+__device__ __forceinline__ IbPack ib_pack()
 {
-    IbSel g;
+    IbPack g;
     const int lane = LANE, rho = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
 #pragma unroll
-    for (int st = 0; st < 2; st++)
+    for (int st = 0; st < 2; st++) {
+        unsigned w = 0u;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int i = 4 * (t >> 1) + rho, j = 4 * (t & 1) + q;
             const bool ok = (i < 6) && (j < 6), tp = (st != 0) != (b < 2);
             const int e = ok ? (tp ? 6 * j + i : 6 * i + j) : 0;
-            g.i[st][t] = c_ib_idx[e];
-            const double sv = c_ib_sgn[e];
-            g.s[st][t] = ok ? sv : 0.0;
+            const int sg = ok ? (int)c_ib_sgn[e] : 0;              // -1, 0, 1
+            w |= ((unsigned)c_ib_idx[e] | (((unsigned)sg & 3u) << 4)) << (6 * t);
+        }
+        g.w[st] = w;
+    }
+    return g;
+}
+__device__ __forceinline__ IbSel ib_unpack(const IbPack &p)
+{
+    IbSel g;
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            g.i[st][t] = (int)((p.w[st] >> (6 * t)) & 15u);
+            g.s[st][t] = (double)(((int)(p.w[st] << (26 - 6 * t))) >> 30);      // sign-extended two-bit field
         }
     return g;
 }
+__device__ __forceinline__ IbSel ib_select() { return ib_unpack(ib_pack()); }
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ void phase_crba_mfma(double *L, const IbSel &g)
 {
@@ -1400,29 +1480,26 @@ __device__ __forceinline__ void phase_crba(LV<R> L, const IbSel &g)
 template <typename R>
 __device__ __forceinline__ void phase_jacobian(LV<R> L)
 {
-    const int lane = LANE;
-    const TreeRows tr = tree_rows();
-    const int r = tr.r, foot = (tr.rho == 1) ? 1 : 0;
-    const bool jon = tr.on6 && tr.rho < 2;
-    const int sole = foot ? 14 : 7;
+    // duplicate-lane form (see tree_dup): no lane exchange happens here at all, so ANY lane that works on (foot, row r) is a valid
+    // repeat -- DPP rows 2, 3 repeat the right / left foot, lanes 6..15 repeat rows -- and every store is unconditional.
+    const TreeDup tr = tree_dup();
+    const int r = tr.r, foot = tr.rho & 1;
+    const LV<R> Xs = L + (A_XF + 36 * 7 + 36 * 7 * foot);          // X_sole; X of frame sole - 1 - s sits 36 (1 + s) below
+    const LV<R> Jo = L + (A_JL + 72 * foot + 12 * r);
     R xn[6];
-    {
-        const LV<R> X = L + A_XF + 36 * sole + 6 * r;              // Xn = X_sole
 #pragma unroll
-        for (int c = 0; c < 6; c++) xn[c] = X[c];
-    }
+    for (int c = 0; c < 6; c++) xn[c] = Xs[6 * r + c];             // Xn = X_sole
     R A_[9], B_[9];
-    auto load_x = [&](int f, R (&a9)[9], R (&b9)[9]) {
-        const LV<R> X = L + A_XF + 36 * f;
+    auto load_x = [&](int below, R (&a9)[9], R (&b9)[9]) {
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) { a9[3 * k + c] = X[6 * k + c]; b9[3 * k + c] = X[6 * (3 + k) + c]; }
+            for (int c = 0; c < 3; c++) { a9[3 * k + c] = Xs[6 * k + c - 36 * below]; b9[3 * k + c] = Xs[6 * (3 + k) + c - 36 * below]; }
     };
-    load_x(sole - 1, A_, B_);
+    load_x(1, A_, B_);
 #pragma unroll
     for (int s = 0; s < 6; s++) {                                  // frame 6..1 / 13..8; the next frame's X is loaded while this one is applied
-        L[jon ? A_JL + 72 * foot + 12 * r + 6 + (5 - s) : (int)P_DUMP] = xn[2];      // Xn S (z column)
+        Jo[6 + (5 - s)] = xn[2];                                   // Xn S (z column)
         R nn[6];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -1430,17 +1507,20 @@ __device__ __forceinline__ void phase_jacobian(LV<R> L)
             nn[3 + c] = xn[3] * A_[c] + xn[4] * A_[3 + c] + xn[5] * A_[6 + c];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s < 5) load_x(sole - 2 - s, A_, B_);
+        if (s < 5) load_x(2 + s, A_, B_);
 #pragma unroll
         for (int c = 0; c < 6; c++) xn[c] = nn[c];
     }
 #pragma unroll
-    for (int c = 0; c < 6; c++) L[jon ? A_JL + 72 * foot + 12 * r + c : (int)P_DUMP] = xn[c];      // base block: row r of the whole product
+    for (int c = 0; c < 6; c++) Jo[c] = xn[c];                     // base block: row r of the whole product
     WSYNC();
-    for (int e = lane; e < 144; e += 64) {                         // rotate to world axes
-        const int ft = e / 72, rr = (e % 72) / 12, col = e % 12, r3 = rr % 3, o = (rr / 3) * 3;
-        const LV<R> T = L + P_TB + 12 * (1 + ft), J = L + A_JL + 72 * ft + col;
-        L[P_JC + e] = T[4 * r3] * J[12 * o] + T[4 * r3 + 1] * J[12 * (o + 1)] + T[4 * r3 + 2] * J[12 * (o + 2)];
+    {   // rotate to world axes: J[ft][3 b + r3][col] = sum_k R_sole[r3][k] JL[ft][3 b + k][col].  DPP row q = (ft, b), lane = column (lanes
+        // 12..15 repeat columns 0..3); three outputs per lane
+        const int lane = LANE, q = lane >> 4, l16 = lane & 15, col = (l16 < 12) ? l16 : l16 - 12, ft = q & 1, b3 = q >> 1;
+        const LV<R> T = L + (P_TB + 12 + 12 * ft), J = L + (A_JL + 72 * ft + 36 * b3 + col), O = L + (P_JC + 72 * ft + 36 * b3 + col);
+        const R j0 = J[0], j1 = J[12], j2 = J[24];
+#pragma unroll
+        for (int r3 = 0; r3 < 3; r3++) O[12 * r3] = T[4 * r3] * j0 + T[4 * r3 + 1] * j1 + T[4 * r3 + 2] * j2;
     }
     WSYNC();
 }
@@ -1593,7 +1673,9 @@ __device__ __forceinline__ void refs_vfoot_pdjoints(double *L, LmhCParams &P)
     }
     if (lane >= 32 && lane < 62) {                                 // PDJointsAcc, controller.cpp:296-308
         const int i = lane - 32;
-        const double val = P.kp_joints * (qdes_of(i) - L[P_Q + i]) + P.kd_joints * (0.0 - L[P_V + i]);
+        // Robot::desiredPosture (Robot.cpp:253-262): coordinates 0..27 ride in the spare slot of the model record (lmh_model_kernel); 28, 29 are 0
+        const double qd0 = L[P_MODEL + LMH_BODY_STRIDE * ((i < 28) ? i : 27) + 13];
+        const double val = P.kp_joints * (((i < 28) ? qd0 : 0.0) - L[P_Q + i]) + P.kd_joints * (0.0 - L[P_V + i]);
         L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
     }
 }
@@ -1980,7 +2062,7 @@ __device__ __forceinline__ int cone_pushthrough(double *L, LmhCParams &P, unsign
     WSYNC();
     {   // (W + eps K^-1) w = h on the rows of the feet that carry force
         double a[12], b[1];
-        const int lr = (lane < 12) ? lane : 0, fi = lr / 6, ri = lr % 6;
+        const int l16 = lane & 15, lr = (l16 < 12) ? l16 : 0, fi = (lr >= 6) ? 1 : 0, ri = lr - 6 * fi;          // (a copy of the system per DPP row)
         const bool rowuse = (lane < 12) && ((fi == 0) ? useR : useL);
         const double eps = P.eps_coeff;
 #pragma unroll
@@ -2290,7 +2372,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
         } else {
         double a[12], b[1];
         {
-            const int lr = (lane < 12) ? lane : 0, fi = lr / 6, ri = lr % 6;
+            const int l16 = lane & 15, lr = (l16 < 12) ? l16 : 0, fi = (lr >= 6) ? 1 : 0, ri = lr - 6 * fi;      // (a copy of the system per DPP row)
             const double eps = P.eps_coeff;
 #pragma unroll
             for (int c = 0; c < 12; c++) {                         // full rows, unconditional loads (Gauss-Jordan)
@@ -2434,17 +2516,22 @@ __device__ __forceinline__ v4d mfma_ptr(const double *a0, const double *b0)
 // two-wave schedule wave 0 writes them while wave 1 is still inside CRBA / its reference chain, ahead of the join.
 __device__ __forceinline__ void qp_prefill15(double *L, LmhCParams &P)
 {
-    const int lane = LANE;
+    // 12 rows x 32 columns, six entries per lane: lane = (row parity rh, column c); the entry of pass `it` is row rh + 2 it, i.e. foot
+    // it / 3, row rh + 2 (it % 3) of that foot's compact store (12 columns: base 6 | own leg 6).  Dense column c of the right foot is compact
+    // column c (c < 12); of the left foot c (c < 6) or c - 6 (12 <= c < 18).  Everything that depends on the lane is formed once; a pass is a
+    // load, two multiplications (by 0 | 1 and by 0 | 1 / D_c) and two stores.
+    const int lane = LANE, c = lane & 31, rh = lane >> 5;
     const double idp = P.inv_w_base_pos, ida = P.inv_w_base_ang, idj = P.inv_w_joints;
+    const double iD = (c < 3) ? idp : (c < 6) ? ida : idj;
+    const bool ok0 = c < 12, ok1 = (c < 6) || (c >= 12 && c < 18);
+    const double m0 = ok0 ? 1.0 : 0.0, m1 = ok1 ? 1.0 : 0.0, d0 = ok0 ? iD : 0.0, d1 = ok1 ? iD : 0.0;
+    const double *p0 = L + (P_JC + 12 * rh + (ok0 ? c : 0)), *p1 = L + (P_JC + 72 + 12 * rh + (ok1 ? ((c < 6) ? c : c - 6) : 0));
+    double *o = L + (Q_U + 34 * rh + c);
 #pragma unroll
     for (int it = 0; it < 6; it++) {
-        const int e = lane + 64 * it, r = e >> 5, c = e & 31, o = 34 * r + c;
-        const bool in = c < 30;
-        const double vj = jdense(L, r, in ? c : 0);
-        const double u = in ? vj : 0.0;
-        const double iD = (c < 3) ? idp : (c < 6) ? ida : idj;
-        L[Q_U + o] = u;
-        L[Q_UD + o] = u * iD;
+        const double v = (it < 3) ? p0[24 * it] : p1[24 * (it - 3)];
+        o[68 * it] = v * ((it < 3) ? m0 : m1);
+        o[68 * it + (Q_UD - Q_U)] = v * ((it < 3) ? d0 : d1);
     }
 }
 
@@ -2468,22 +2555,31 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
     const int tr = lane & 15, tq = lane >> 4;                      // fragment row / k-quarter; result rows tq + 4 reg, column tr
     // ---- fills: U, U D^-1 (padded 16 x 32; row order: 12 Jacobian rows, 3 linear-momentum rows, one zero row), bp'' (8 x 32), weights
     if constexpr (NW == 1) qp_prefill15(L, P);                     // NW = 2: wave 0 has already written the Jacobian rows (controller_eval)
-    for (int e = lane; e < ((wid == NW - 1) ? 128 : 0); e += 64) { // rows 12..15: the helper wave (wave 0 forms AGpqp and the weights meanwhile)
-        const int r = 12 + (e >> 5), c = e & 31, o = 34 * r + c;
-        const bool in = (r < nU) && (c < 30);
-        const double va = L[P_AG + 30 * (3 + (in ? r - 12 : 0)) + (in ? c : 0)];
-        const double u = in ? va : 0.0;
-        const double iD = (c < 3) ? idp : (c < 6) ? ida : idj;
-        L[Q_U + o] = u;
-        L[Q_UD + o] = u * iD;
-    }
-    for (int e = lane + 64 * wid; e < 224; e += 64 * NW) {         // rows 0..6 of bp'' (row 7 follows the join)
-        const int n = e >> 5, i = e & 31;
-        const bool in = i < 30;
-        const int is = in ? i : 0;
-        const double iDi = (i < 3) ? idp : (i < 6) ? ida : idj;
-        const double vq = -L[P_QREF + is], vm = L[P_MTOP + 30 * ((n > 0) ? n - 1 : 0) + is] * iDi;
-        L[Q_BPT + 34 * n + i] = in ? ((n == 0) ? vq : vm) : 0.0;
+    {   // lane = (row parity hi, column c); everything derived from the lane once, a pass is a load, one or two multiplications and the stores
+        const int c = lane & 31, hi = lane >> 5, cs = (c < 30) ? c : 0;
+        const double iDc = (c < 3) ? idp : (c < 6) ? ida : idj, dm = (c < 30) ? iDc : 0.0;          // 1 / D_c, 0 on the padding columns
+        if (wid == NW - 1) {                                       // rows 12..15 of U, U D^-1: the helper wave (wave 0 forms AGpqp and the weights meanwhile)
+            const double um = (c < 30) ? 1.0 : 0.0;
+            const double *ag = L + (P_AG + 90 + 30 * hi + cs);     // linear-momentum rows 3..5 of AG -> operand rows 12..14; row 15 is zero
+            double *o = L + (Q_U + 34 * (12 + hi) + c);
+            const double v0 = ag[0], v1 = ag[(hi == 0) ? 60 : 0];
+            o[0] = v0 * um; o[Q_UD - Q_U] = v0 * dm;
+            o[68] = hi ? 0.0 : v1 * um; o[68 + (Q_UD - Q_U)] = hi ? 0.0 : v1 * dm;
+        }
+        // rows 0..6 of bp'' = [-qref | D^-1 Mb'] (row 7 follows the join): wave w, row parity hi -> rows hi + 2 w and hi + 2 w + 4
+        const int n0 = hi + 2 * ((NW == 2) ? wid : 0);
+        {
+            const double *pa = L + ((n0 == 0) ? P_QREF + cs : P_MTOP + 30 * (n0 - 1) + cs);
+            const double sa = (n0 == 0) ? ((c < 30) ? -1.0 : 0.0) : dm;
+            L[Q_BPT + 34 * n0 + c] = pa[0] * sa;
+            const double *pb = L + (P_MTOP + 30 * (n0 + 3) + cs);  // rows 4, 5 (wave 0) | 6 (wave 1; row 7 is not a row of Mb: the store goes to the trash)
+            L[(n0 < 3) ? Q_BPT + 34 * (n0 + 4) + c : Q_TRASH + lane] = ((n0 < 3) ? pb : pa)[0] * dm;
+        }
+        if constexpr (NW == 1) {                                   // single-wave schedule: the other two row pairs as well
+            const int n1 = hi + 2;
+            L[Q_BPT + 34 * n1 + c] = L[P_MTOP + 30 * (n1 - 1) + cs] * dm;
+            if (hi == 0) L[Q_BPT + 34 * 6 + c] = L[P_MTOP + 30 * 5 + cs] * dm;
+        }
     }
     if (wid == 0) {                                                // wave 0: it has just formed AGpqp (phase_qp)
         if (lane < 16) {                                           // Om_r beta_r | 1 / Om_r | beta_r  (row 15: zeros)
@@ -2536,7 +2632,7 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
     // ---- Cm t = V (7 right-hand sides): wave 0  |  Z = Mb D^-1 U', Mb bp': helper wave
     if (NW == 1 || wid == 0) {
         double a[nU], bb[7];
-        const int lr = (lane < 16) ? lane : 0;
+        const int lr = lane & 15;                                  // every 16-lane DPP row carries a copy of the system (gj_solve_regs)
 #pragma unroll
         for (int c = 0; c < nU; c++) a[c] = L[Q_CM + 17 * lr + c];
 #pragma unroll
@@ -2601,12 +2697,12 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
             // ~cond(S) more digits and leaves S^-1 (hence W) unsymmetric at the 1e-10 level, which the active-set tests of the cone QP
             // (tolerances ~1e-14) do not survive: LDL' on the lower triangle here.
             double a[6], bb[6];
-            const int lr = (lane < 6) ? lane : 0;
+            const int l16 = lane & 15, lr = (l16 < 6) ? l16 : 0;   // (a copy of the system per DPP row)
             // Gauss-Jordan on the full S, then S^-1 <- (S^-1 + S^-T) / 2: plain Gauss-Jordan leaves S^-1 (hence W) unsymmetric at the 1e-10 level (it loses
             // ~cond(S) more digits than LDL'), which the active-set tests of the cone QP (tolerances ~1e-14) do not survive; symmetrised, W is symmetric to
             // round-off again and the solve is 1.5k cycles shorter than LDL' with its parked factor (LMH_LDL_SI keeps that form for comparison)
 #pragma unroll
-            for (int c = 0; c < 6; c++) { a[c] = L[Q_S + 7 * lr + c]; bb[c] = (lane == c) ? 1.0 : 0.0; }
+            for (int c = 0; c < 6; c++) { a[c] = L[Q_S + 7 * lr + c]; bb[c] = (l16 == c) ? 1.0 : 0.0; }
             if (gj_solve_regs<6, 6>(a, bb, 0x3Fu)) flags |= LMH_FLAG_NOT_SPD;
 #pragma unroll
             for (int c = 0; c < 6; c++) L[(lane < 6) ? Q_LS + 6 * lane + c : Q_TRASH + lane] = bb[c];
@@ -2758,7 +2854,7 @@ __device__ __forceinline__ int qp_setup(double *L, LmhCParams &P, int wid, doubl
         double a[NU], bb[7];
         const bool on = lane < nU;
         if constexpr (NU <= 16) {                                  // Gauss-Jordan on full rows
-            const int lr = on ? lane : 0;
+            const int lr = ((lane & 15) < nU) ? (lane & 15) : 0;   // (a copy of the system per DPP row)
 #pragma unroll
             for (int c = 0; c < NU; c++) a[c] = L[B_CF + 18 * lr + c];
 #pragma unroll
@@ -3107,7 +3203,7 @@ __device__ __forceinline__ void phase_plant(double *L, LmhCParams &P)
     WSYNC();
     {
         double a[6], b[1];
-        const int lr = (lane < 6) ? lane : 0;
+        const int l16 = lane & 15, lr = (l16 < 6) ? l16 : 0;       // (a copy of the system per DPP row)
 #pragma unroll
         for (int c = 0; c < 6; c++) a[c] = L[PL_SB + 7 * lr + 1 + c];
         b[0] = L[PL_SB + 7 * lr];
@@ -3176,7 +3272,8 @@ __device__ __forceinline__ void phase_outputs_qdd(double *L, int a_src = P_A)
 // PIPE (rollout kernel only): the kinematics of this evaluation were run ahead by the helper wave, inside the previous evaluation's
 // `window` (phase_qp), and so were the clock-only references; wave 0 starts at the X images.
 template <int NW, typename R, bool QF32 = false, bool PIPE = false, class WF = NoWindow>
-__device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg, bool need_tau = true, WF window = WF())
+__device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int inst, double t, int wid, unsigned *Fmask, int *k_out, int *iters_out, double *dbg, bool need_tau = true, WF window = WF(),
+                                               const IbPack *ibp = nullptr)
 {
     int flags = 0, ph = 0;
     // in-kernel stamps (debug build of the kernel only): s_memtime at the phase boundaries
@@ -3184,7 +3281,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     STAMP(0);
     WSTAMP(0);
     IbSel ibsel;                                                   // gather tables of the matrix-core CRBA: constant-memory loads, issued long before their use
-    if constexpr (std::is_same_v<R, double>) { if (NW == 1 || wid == 1) ibsel = ib_select(); }
+    if constexpr (std::is_same_v<R, double>) { if (NW == 1 || wid == 1) ibsel = ibp ? ib_unpack(*ibp) : ib_select(); }
     if (NW == 2 && wid == 1 && !PIPE) {
         // while wave 0 runs the forward kinematics: the clock-only references, then K_f^-1 of the free set the cone solve will start from
         refs_prepare(L, P, inst, t);
@@ -3530,6 +3627,8 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     if (PIPE && wid == 1) refs_prepare(L, P, inst, t);             // clock-only references of the first evaluation (needs load_common's cache reset)
     int k = 0, iters = 0, flags = 0, itmax = 0;
     if (tick0 > 0) { itmax = status[LMH_STATUS_STRIDE * inst + 1]; flags = status[LMH_STATUS_STRIDE * inst + 2]; }      // status[1], [2] cover the whole launch
+    IbPack ibp = {{0u, 0u}};
+    if constexpr (std::is_same_v<R, double>) ibp = ib_pack();      // the matrix-core CRBA's gather table, two registers for the whole chunk
     const double dt = P.dt;
 #ifdef LMH_SUBSTAMPS
     if (lane == 0) { L[D_BWAIT + wid] = 0.0; for (int j_ = 0; j_ < 8; j_++) L[D_JWAIT + 8 * wid + j_] = 0.0; }
@@ -3570,7 +3669,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
                     WSTAMP(70);
                 }
             };
-            flags |= controller_eval<2, R, QF32, PIPE, decltype(window)>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3, window);
+            flags |= controller_eval<2, R, QF32, PIPE, decltype(window)>(L, *Pe, inst, ts, wid, &F, &k, &iters, nullptr, stage == 3, window, &ibp);
             WSTAMP(71);
             if (wid == 0) {
                 itmax = (iters > itmax) ? iters : itmax;
@@ -3707,7 +3806,7 @@ __global__ void __launch_bounds__(64) lmh_model_kernel(const double *raw, double
                 mo[3 * a + b] = I2[3 * a + b] - (m * cc);
             }
         for (int a = 0; a < 3; a++) mo[9 + a] = m * c[a];
-        mo[12] = m; mo[13] = 0.0;
+        mo[12] = m; mo[13] = qdes_of(lane);                       // the record's spare slot: Robot::desiredPosture of coordinate `lane` (PDJointsAcc)
         mloc = m;
     }
     // mass_ += links_[i].mass in frame order (Robot.cpp:21)
