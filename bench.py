@@ -651,6 +651,10 @@ def main():
                          "counted": counted,
                          "note": "binding resource: fp64 vector issue + LDS latency (SURVEY 8d); `frac` prices SURVEY's nominal 8.0e5 flop per tick, `frac_counted` the fp64 operations "
                                  "the kernel actually issues (PMC instruction classes of the committed profile)",
+                         "nominal_flop_skipped_by_design": "of SURVEY's nominal 2.0e5 flop per evaluation the kernel does not perform: tau = M a + C - J'w at three of the four RK4 stages "
+                                 "(the integrator never reads it; k4 only: ~2.6e3 flop per skipped evaluation), the angular-momentum rows of AG / AGpqp / h (weight 0 in the reference: ~3e3 flop), "
+                                 "the MPC Hessian / spatial-inertia / friction-block rebuilds of quirk A8 (constants), and SURVEY's nominal 15 working-set changes of the contact QP "
+                                 "(~7e4 flop; a warm-started exact solve takes 1 round) -- which is why frac (nominal) and frac_counted (issued) are reported side by side",
                          "hbm": {"bound": "hbm", "achieved": hbm_g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_g / HBM_PEAK_GBS},
                          "mfma": mfma},
             "instances_flagged": hard,

@@ -361,6 +361,12 @@ extern "C" int lmh_set_model(lmh_handle *h, const double *raw, int n_models)
     if (!h) return fail(LMH_ERR_BAD_ARG, "null handle");
     if (!raw) { raw = &kLmhNaoLinks[0][0]; n_models = 1; }
     if (n_models != 1 && n_models != h->B) return fail(LMH_ERR_BAD_ARG, "n_models must be 1 or n_instances");
+    // frames 7, 14 (soles) and 27 (extra head frame) are massless virtual frames in createNaoParameters (src/robotParameters.cpp); the
+    // kernels' tree recursions rely on that (they carry no body force and no inertia there)
+    for (int m = 0; m < n_models; m++)
+        for (int f : {7, 14, 27})
+            for (int e = 0; e < LMH_LINK_STRIDE; e++)
+                if (raw[((size_t)m * 28 + f) * LMH_LINK_STRIDE + e] != 0.0) return fail(LMH_ERR_BAD_ARG, "lmh_set_model: frames 7, 14, 27 are massless virtual frames: their records must be zero");
     HIPCHK(hipSetDevice(h->device));
     if (h->d_raw) { HIPCHK(hipFree(h->d_raw)); h->d_raw = nullptr; }
     if (h->d_model) { HIPCHK(hipFree(h->d_model)); h->d_model = nullptr; }
@@ -423,7 +429,8 @@ extern "C" int lmh_set_foot_coeffs(lmh_handle *h, const double *r, const int32_t
     for (int a = 0; a < 3; a++) {
         if (rn[a] < 1 || rn[a] > 8 || ln[a] < 1 || ln[a] > 8) return fail(LMH_ERR_BAD_ARG, "coefficient count must be 1..8");
         h->P.rFn[a] = rn[a]; h->P.lFn[a] = ln[a];
-        for (int k = 0; k < 8; k++) { h->P.rF[a][k] = r[8 * a + k]; h->P.lF[a][k] = l[8 * a + k]; }
+        // entries beyond the count are stored as zeros: the kernels evaluate all eight terms (a zero coefficient adds an exact zero)
+        for (int k = 0; k < 8; k++) { h->P.rF[a][k] = (k < rn[a]) ? r[8 * a + k] : 0.0; h->P.lF[a][k] = (k < ln[a]) ? l[8 * a + k] : 0.0; }
     }
     return LMH_OK;
 }

@@ -413,13 +413,15 @@ __device__ __forceinline__ void dpp_fmac_rhs(double (&b)[M], double m)
 }
 
 // One pivot of the row-per-lane LDL' for N <= 16 (all rows inside DPP row 0), then the next (compile-time recursion).
+// `dadd`: a constant on the diagonal of the matrix, added where the pivot is read (the diagonal entry is touched nowhere else: lane J's own
+// column entry is only ever used through this broadcast), so that the caller does not have to place it with a select per column.
 template <int J, int N, int M>
-__device__ __forceinline__ void ldl16_forward(double (&a)[N], double (&b)[M], unsigned live, int lane, int &bad, double &myinv)
+__device__ __forceinline__ void ldl16_forward(double (&a)[N], double (&b)[M], unsigned live, int lane, int &bad, double &myinv, double dadd = 0.0)
 {
     if constexpr (J < N) {
         if ((live >> J) & 1u) {                                   // wave-uniform
-            double d = bcast16<J>(a[J]);
-            d = (lane < 16) ? d : 1.0;                            // DPP rows 1..3 hold no matrix rows
+            // (DPP rows 1..3 hold no matrix rows: whatever they compute -- possibly non-finite -- stays in their lanes; `bad` is read from lane 0)
+            const double d = bcast16<J>(a[J]) + dadd;
             if (!(d > 0.0)) bad = 1;
             const double invd = fast_rcp(d);
             const double f = a[J] * invd;                         // L_iJ in lanes i > J
@@ -427,9 +429,9 @@ __device__ __forceinline__ void ldl16_forward(double (&a)[N], double (&b)[M], un
             if (lane == J) myinv = invd;
             dpp_fmac_tail<J + 1>(a, a[J], -f);                    // a[c] -= f * (d_J L_cJ held by lane c)
             dpp_fmac_rhs<J>(b, nfm);                              // forward substitution
-            if (lane > J) a[J] = f;
+            a[J] = f;                                             // (rows <= J keep a don't-care there: only L_iJ, i > J, is read back)
         }
-        ldl16_forward<J + 1>(a, b, live, lane, bad, myinv);
+        ldl16_forward<J + 1>(a, b, live, lane, bad, myinv, dadd);
     }
 }
 template <int J, int N, int M>
@@ -541,14 +543,14 @@ __device__ __forceinline__ int ldl2_solve_regs(double (&a0)[16], double (&a1)[16
 // factorisation); the rows of L are parked once in Ls (row stride N+1, conflict free) for the backward
 // substitution.  On exit b[r] of lane i holds x_i.  Returns non-zero (wave-uniform) if a pivot was not positive.
 template <int N, int M>
-__device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], unsigned live, double *Ls)
+__device__ __forceinline__ int ldl_solve_regs(double (&a)[N], double (&b)[M], unsigned live, double *Ls, double dadd = 0.0)
 {
     const int lane = LANE;
     int bad = 0;
     double myinv = 0.0;                                           // 1 / d_lane (0 on rows that are not live)
     if constexpr (N <= 16) {
         WSTAMP(40);
-        ldl16_forward<0>(a, b, live, lane, bad, myinv);
+        ldl16_forward<0>(a, b, live, lane, bad, myinv, dadd);
         bad = __builtin_amdgcn_readfirstlane(bad);
 #pragma unroll
         for (int r = 0; r < M; r++) b[r] *= myinv;                // w = D^-1 z
@@ -727,19 +729,24 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0
 {
     const int lane = LANE;
     constexpr int RPY = AHEAD ? (int)A_T0S + 12 : (int)P_SC + 50;
-    // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos
-    // lane = (slot fr < 5, entry el < 12): five of the 28 local transforms per round, six rounds
-    const int lfr = (lane < 60) ? lane / 12 : 0, lel = lane % 12;
-    // an entry takes at most one trigonometric term, and which one depends on its position in the 3 x 4 only (Khalil DH: columns 0, 1
-    // of every row; cos in (0,0), (1,1), (2,1), sin in (0,1), (1,0), (2,0)): two coefficients per entry are loaded, not three
+    // lane = (slot fr < 5, entry el < 12) for the local transforms AND (chain c = fr, entry el) for the chain products; lanes 60..63 repeat
+    // lanes 0..3 (the first row of chain 0: a complete quad, so its quad broadcasts see what lanes 0..3 see) -- no lane is switched off, and
+    // everything derived from the lane is formed once.
+    const unsigned l60 = (unsigned)((lane < 60) ? lane : lane - 60);
+    const int lfr = (int)(__umul24(l60, 43u) >> 9), lel = (int)l60 - 12 * lfr;       // l60 / 12, l60 % 12 (exact below 60)
+    // DH coefficient loads (L2-resident table) are issued first: their latency hides behind the sincos.  Five of the 28 local transforms
+    // per round, six rounds.  An entry takes at most one trigonometric term, and which one depends on its position in the 3 x 4 only
+    // (Khalil DH: columns 0, 1 of every row; cos in (0,0), (1,1), (2,1), sin in (0,1), (1,0), (2,0)): two coefficients per entry are loaded
     const bool cosT = (lel == 0) || (lel == 5) || (lel == 9);
     const int ksel = cosT ? 1 : 2;
     R c0[6], ck[6];
+    {
+        const LV<R> cf = lcoef + 3 * (12 * lfr + lel), cf5 = lcoef + 3 * (12 * ((lfr < 3) ? 25 + lfr : 27) + lel);     // round 5: slots 25..27 (28, 29 do not exist)
 #pragma unroll
-    for (int u = 0; u < 6; u++) {
-        const int sl = 5 * u + lfr;
-        const LV<R> cf = lcoef + 3 * (12 * ((sl < 28) ? sl : 0) + lel);
-        c0[u] = cf[0]; ck[u] = cf[ksel];
+        for (int u = 0; u < 6; u++) {
+            const LV<R> cu = (u < 5) ? cf + 180 * u : cf5;
+            c0[u] = cu[0]; ck[u] = cu[ksel];
+        }
     }
     const double dh_off = c_dh_off[(lane < 24) ? lane : 0];        // theta offsets, Robot.cpp:59-87 (constant memory, L2-resident like lcoef)
     R qa = (R)0, qpos = (R)0;
@@ -766,13 +773,11 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0
     // c0 + c1 cos(theta) + c2 sin(theta) with model constants (c0, c1, c2) tabulated once on the host
     // (lcoef, L2-resident); the zero / one coefficients make the fused form bit-identical to the products.
     {
+        // slot 5 u + fr: its sin | cos sit at P_SC + 2 slot (slots 25..27 are constants, c1 = c2 = 0: what is read there only has to be
+        // finite); round 5 also "writes" slots 28, 29 -- the chain products' own first step overwrites those two (T0 aux), nobody reads them
+        const LV<R> sc = L + (P_SC + 2 * lfr + (cosT ? 1 : 0)), o = L + (A_LC + 12 * lfr + lel);
 #pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const int sl = 5 * u + lfr;
-            const int ss = (sl < 25) ? sl : 24;                    // slots 25..27 are constants (c1 = c2 = 0)
-            const R val = fma(ck[u], (R)L[P_SC + 2 * ss + (cosT ? 1 : 0)], c0[u]);
-            if (lane < 60 && sl < 28) L[A_LC + 12 * sl + lel] = val;
-        }
+        for (int u = 0; u < 6; u++) o[60 * u] = fma(ck[u], (R)sc[10 * u], c0[u]);
     }
     if (lane < 12) {                                               // T0 = [R(rpy) p]
         const int r = lane >> 2, col = lane & 3;
@@ -791,29 +796,40 @@ __device__ __forceinline__ void phase_fk(LV<R> L, const LV<R> lcoef, R qn = (R)0
     // row of T_src comes from three quad broadcasts (DPP quad_perm) instead of an LDS store / fence / load per step; the local transforms
     // do not depend on the recurrence: all 24 of a lane are loaded before its first step, and from there on the world transforms are
     // written over them (A_T and A_LC are the same 360 doubles).
-    const int c = (lane < 60) ? lane / 12 : 4, el = lane % 12, col = el & 3;
+    // Schedule (Robot.cpp:120-158): legs (c < 2): step 0 = T0 * aux (local slot 25 + c -> T slot 28 + c), steps 1..6 the joints (local
+    // 6 c + s - 1 -> T 7 c + s), step 7 the sole (local 27 -> T 7 c + 7); arms (c = 2, 3): steps 0..4 (local 5 c + 2 + s -> T 5 c + 5 + s);
+    // head (c = 4): steps 0..2 (local 22 + s -> T 25 + s).  So local slot and T slot of a step are (per-lane base) + s except at the
+    // legs' ends; a step a chain does not have works on whatever valid slot that gives and stores into T slot 28 / 29, which nobody reads.
+    const int c = lfr, el = lel, col = el & 3;
+    const bool leg = c < 2, head = c == 4;
+    const int lb = leg ? 6 * c - 1 : head ? 22 : 5 * c + 2;        // local slot of step s = lb + s
+    const int db = leg ? 7 * c : head ? 25 : 5 * c + 5;            // T slot of step s = db + s
     WSYNC();
     R tcur = L[A_T0S + el];                                        // T0 (every chain starts from the base)
     R l0[8], l1[8], l2[8];
+    {
+        const LV<R> Lr = L + (A_LC + 12 * lb + col), L0 = leg ? L + (A_LC + 12 * (25 + c) + col) : Lr, L7 = leg ? L + (A_LC + 12 * 27 + col) : Lr + 84;
 #pragma unroll
-    for (int s = 0; s < 8; s++) {                                  // all 24 operand loads before the first dependent step
-        int dst, src, loc;
-        fk_sched(c, s, &dst, &src, &loc);
-        const LV<R> Lo = L + A_LC + 12 * (((lane < 60) && (dst >= 0)) ? loc : 0) + col;
-        l0[s] = Lo[0]; l1[s] = Lo[4]; l2[s] = Lo[8];
+        for (int s = 0; s < 8; s++) {                              // all 24 operand loads before the first dependent step
+            const LV<R> Lo = (s == 0) ? L0 : (s == 7) ? L7 : Lr + 12 * s;
+            l0[s] = Lo[0]; l1[s] = Lo[4]; l2[s] = Lo[8];
+        }
     }
     WSYNC();                                                       // every lane has its local transforms: their place is free
     if (lane < 12) L[A_T + lane] = tcur;
+    {
+        const R m3 = (col == 3) ? (R)1 : (R)0;
+        const LV<R> Dr = L + (A_T + 12 * db + el), Dx = L + (A_T + 12 * 28 + el);        // regular destination of step s: Dr + 12 s | the unread slot
+        const LV<R> D0 = leg ? Dx + 12 * c : Dr;
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
-        int dst, src, loc;
-        fk_sched(c, s, &dst, &src, &loc);
-        const bool on = (lane < 60) && (dst >= 0);
-        const R t0 = dpp_row<0x00>(tcur), t1 = dpp_row<0x55>(tcur), t2 = dpp_row<0xAA>(tcur), t3 = dpp_row<0xFF>(tcur);
-        R val = t0 * l0[s] + t1 * l1[s] + t2 * l2[s];
-        val += (col == 3) ? t3 : 0.0;
-        if (on) L[A_T + 12 * dst + el] = val;
-        tcur = on ? val : tcur;
+        for (int s = 0; s < 8; s++) {
+            const R t0 = dpp_row<0x00>(tcur), t1 = dpp_row<0x55>(tcur), t2 = dpp_row<0xAA>(tcur), t3 = dpp_row<0xFF>(tcur);
+            R val = t0 * l0[s] + t1 * l1[s] + t2 * l2[s];
+            val = fma(t3, m3, val);                                // + T[r][3] in the translation column
+            const LV<R> D = (s == 0) ? D0 : (s < 3) ? Dr + 12 * s : (s < 5) ? (head ? Dx : Dr + 12 * s) : (leg ? Dr + 12 * s : Dx);
+            D[0] = val;
+            tcur = val;
+        }
     }
     WSYNC();
 }
@@ -1354,38 +1370,61 @@ __device__ __forceinline__ IbSel ib_unpack(const IbPack &p)
 }
 __device__ __forceinline__ IbSel ib_select() { return ib_unpack(ib_pack()); }
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+#define CR_DUMP (S0 + 1000)        // 72 doubles nobody reads during the tree phases: S0 + [952, 1200) is the one stretch neither wave 0's Newton-Euler arrays
+                                   // nor its early Jacobian rows of U, U D^-1 (qp_prefill15: up to S0 + 952) touch.  The store pointers of idle lanes point
+                                   // at CR_DUMP + 24 and are used with level offsets in [-23, 42]
 __device__ __forceinline__ void phase_crba_mfma(double *L, const IbSel &g)
 {
     const int lane = LANE;
     SUBSTAMP(9);
+    // Everything that depends on the lane is formed ONCE, as pointers: a level then addresses (per-lane base) + (compile-time offset of the
+    // level), and a lane that has nothing to store at some place holds the dump region's address in that pointer -- no select per store.
+    // Block 3 (left arm) repeats block 2's head frames at levels 0, 1 (same inputs, same instructions: the stores carry the same bits), and
+    // the legs run their massless sole at level 0 on zeros (lmh_set_model insists on that), so no level switches a block off.
     const int rho = lane >> 4, b = (lane >> 2) & 3, q = lane & 3;
-    const bool leg = b < 2;
-    const int fbB = (b == 0) ? 1 : (b == 1) ? 8 : (b == 2) ? 15 : 20, fbA = (b == 2) ? 20 : fbB;
-    const int jst = (b == 0) ? 0 : (b == 1) ? 6 : (b == 2) ? 12 : 17;
+    const bool leg = b < 2, r2 = rho == 2;
+    const int fb = leg ? 1 + 7 * b : 5 + 5 * b;                   // 1, 8, 15, 20: frames of levels 2..6 = fb + d (d = 6 - level)
+    const int jst = leg ? 6 * b : 2 + 5 * b;                      // 0, 6, 12, 17: first joint of the limb
+    const int dh = leg ? 0 : 20 - fb;                             // levels 0, 1: the legs go on (sole, ankle roll), both arm blocks work on the head (26, 25)
+    double *const dump = L + (CR_DUMP + 24);
     // (the matrix-core tiles of the QP set-up read two entries past row 5 of P_MTOP, i.e. P_HL[0..1], against zero padding: H has to be
     // finite in EVERY evaluation, also in the ones whose torques nobody asks for -- found with the -DLMH_POISON build)
-    for (int e = lane; e < 144; e += 64) L[P_HL + e] = 0.0;        // entries outside a limb's block stay zero
+    L[P_HL + lane] = 0.0; L[P_HL + 64 + lane] = 0.0; L[(lane < 16) ? P_HL + 128 + lane : (int)CR_DUMP] = 0.0;       // entries outside a limb's block stay zero
     // X tiles: element (4 tk + rho, 4 tj + q) of the frame's image; outside the 6 x 6 -> a stored zero of the image (row 0, column 3)
-    int xo[4];
+    int xo[4], xt[4];
+    bool tin[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) { const int i = 4 * (t >> 1) + rho, j = 4 * (t & 1) + q; xo[t] = (i < 6 && j < 6) ? 6 * i + j : 3; }
+    for (int t = 0; t < 4; t++) {
+        const int i = 4 * (t >> 1) + rho, j = 4 * (t & 1) + q;
+        tin[t] = (i < 6) && (j < 6);
+        xo[t] = tin[t] ? 6 * i + j : 3; xt[t] = 6 * j + i;
+    }
+    const double *xp[4], *mp[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        xp[t] = L + (A_XF + 36 * fb + xo[t]);
+        mp[0][t] = L + (P_MODEL + LMH_BODY_STRIDE * fb + g.i[0][t]); mp[1][t] = L + (P_MODEL + LMH_BODY_STRIDE * fb + g.i[1][t]);
+    }
+    // store pointers (see the level loop): joint-space inertia P_HL[6 a + local column], F2 columns P_MTOP[30 row + 6 + joint]
+    const bool ex0 = q >= (leg ? 1 : 2), ex1 = q <= 2;            // column slot 4 tj + q belongs to the limb (legs: 1..6, arms: 2..6)
+    double *const pD = (r2 && q == 2) ? L + (P_HL + 6 * jst) : dump;                                   // H(a, a): + 7 d
+    double *const pDh = (r2 && q == 2 && !leg) ? L + (P_HL + 6 * 22 - 35) : dump;                      // the head's: + 7 d (d = 6, 5)
+    double *const pH1[2] = {(r2 && ex0) ? L + (P_HL + 6 * jst - q) : dump, (r2 && ex1) ? L + (P_HL + 6 * jst - q) : dump};                  // H(parent, column): + 6 d - 4 tj
+    double *const pH2[2] = {(r2 && ex0) ? L + (P_HL + 6 * jst - 6 * q + 35) : dump, (r2 && ex1) ? L + (P_HL + 6 * jst - 6 * q + 35) : dump}; // H(column, parent): + d - 24 tj
     double Z[4] = {0, 0, 0, 0}, F[4] = {0, 0, 0, 0};              // tiles t = 2 (row tile) + (column tile)
     double xb[4], ib[4];
     auto load_ops = [&](int it, double (&x4)[4], double (&i4)[4]) {
         const int d = 6 - it;
-        const int f = ((d < 5) ? fbB : fbA) + d;
-        const double *X = L + A_XF + 36 * f, *mo = L + P_MODEL + LMH_BODY_STRIDE * f;
 #pragma unroll
-        for (int t = 0; t < 4; t++) { x4[t] = X[xo[t]]; i4[t] = mo[g.i[it & 1][t]]; }
+        for (int t = 0; t < 4; t++) {
+            if (it >= 2) { x4[t] = xp[t][36 * d]; i4[t] = mp[it & 1][t][LMH_BODY_STRIDE * d]; }
+            else { x4[t] = (xp[t] + 36 * dh)[36 * d]; i4[t] = (mp[it & 1][t] + LMH_BODY_STRIDE * dh)[LMH_BODY_STRIDE * d]; }
+        }
     };
     load_ops(0, xb, ib);
 #pragma unroll
     for (int it = 0; it < 7; it++) {
         const int d = 6 - it;
-        const bool active = (it >= 2) || (it == 1 && b != 3) || (it == 0 && b == 2);
-        const bool root = (it == 6) || (it == 1 && b == 2);
-        const bool head = (it < 2) && (b == 2);                    // block 2 folds the head first (frames 26, 25), then 19..15
-        const int jbase = head ? 22 : jst, dl = head ? d - 5 : d;  // this frame's joint = jbase + dl
         const bool par = ((it & 1) != 0) != leg;                   // true: the stored matrix is Ic'
         // ---- stored composite inertia of this frame: body inertia (gathered with the parity) + what the child handed up
         double M[4];
@@ -1401,10 +1440,13 @@ __device__ __forceinline__ void phase_crba_mfma(double *L, const IbSel &g)
             const bool sel0 = !par && (q == qc);                   // M = Ic: column 2 is (rho, q = 2) of tiles (0,0), (1,0): quad broadcast
             const double v0 = dpp_row<0xAA>(M[0]), v1 = dpp_row<0xAA>(M[2]);
             F[tc] = sel0 ? v0 : F[tc]; F[2 + tc] = sel0 ? v1 : F[2 + tc];
-            const double E = (par && rho == 2 && q == qc) ? 1.0 : 0.0;   // M = Ic': (M' e_2) e_slot' as a product (A = M tiles (0, ti): k tile 0 holds k = 2)
+            const double E = (par && r2 && q == qc) ? 1.0 : 0.0;   // M = Ic': (M' e_2) e_slot' as a product (A = M tiles (0, ti): k tile 0 holds k = 2)
             F[tc] = MFMA4(M[0], E, F[tc]); F[2 + tc] = MFMA4(M[1], E, F[2 + tc]);
         }
-        L[(active && rho == 2 && q == 2) ? P_HL + 6 * (jbase + dl) + dl : (int)P_DUMP] = M[0];    // H(a, a) = Ic[2][2] (either parity)
+        // H(a, a) = Ic[2][2] (either parity): joint a = jst + d (levels 2..6, the legs' level 1) | 22 + d - 5 (the head, arm blocks at levels 0, 1)
+        if (it >= 2) pD[7 * d] = M[0];
+        else if (it == 1) (leg ? pD : pDh)[7 * d] = M[0];
+        else (leg ? dump : pDh)[7 * d] = M[0];                     // (level 0 of a leg is the massless sole)
         // ---- Y = M' X (A tile (ti, tk) = M tile (tk, ti)), Zn = X' Y (A tile (ti, tk) = X tile (tk, ti)), Fn = X' F
         const double y0 = MFMA4(M[2], x2, MFMA4(M[0], x0, 0.0)), y1 = MFMA4(M[2], x3, MFMA4(M[0], x1, 0.0));
         const double y2 = MFMA4(M[3], x2, MFMA4(M[1], x0, 0.0)), y3 = MFMA4(M[3], x3, MFMA4(M[1], x1, 0.0));
@@ -1414,34 +1456,39 @@ __device__ __forceinline__ void phase_crba_mfma(double *L, const IbSel &g)
         else { Fn[1] = 0.0; Fn[3] = 0.0; }
         Zn[0] = MFMA4(x2, y2, MFMA4(x0, y0, 0.0)); Zn[1] = MFMA4(x2, y3, MFMA4(x0, y1, 0.0));
         Zn[2] = MFMA4(x3, y2, MFMA4(x1, y0, 0.0)); Zn[3] = MFMA4(x3, y3, MFMA4(x1, y1, 0.0));
-        // ---- what the columns leave behind: H(parent joint, column joint) = (X' f)[2] on the way, F2 at the limb root
-        {
-            const int pj_l = dl - 1, pj = jbase + pj_l;            // parent joint of this frame (not at a root)
+        // ---- what the columns leave behind.  Column slot ci = 4 tj + q was created at level ci: its joint sits at depth 6 - ci of the limb.
+        // On the way up: H(parent joint of this frame, column joint) = H(column joint, parent joint) = (X' f)[2] (row 2: lanes rho = 2):
+        //   P_HL[6 (jst + d - 1) + 6 - ci] = pH1[6 d - 4 tj],   P_HL[6 (jst + 6 - ci) + d - 1] = pH2[d - 24 tj].
+        // A slot whose column does not exist YET (ci > level) holds zeros and stores them into entries of joints further up, which get their
+        // values at later levels; slots that never belong to the limb are switched off in the pointers (ex0, ex1).
+        if (it == 6) {                                             // every limb is at its root: the columns are F2 (rows 0..3 here, 4, 5 from the second row tile)
 #pragma unroll
-            for (int tj = 0; tj < ((it >= 4) ? 2 : 1); tj++) {
-                const int ci = 4 * tj + q;                         // column slot = iteration that created the column
-                const bool chead = ci < 2 && b == 2 && it < 2;
-                const int cj_l = chead ? 1 - ci : 6 - ci, cj = (chead ? 22 : jst) + cj_l;
-                const bool exists = (ci <= it) && ((b == 2) ? (it < 2 ? true : ci >= 2) : (b == 3 ? ci >= 2 : ci >= 1));
-                const bool st = active && exists;
-                const bool hrow = st && !root && rho == 2;         // row 2 of X' F
-                L[(st && root) ? P_MTOP + 30 * rho + 6 + cj : hrow ? P_HL + 6 * pj + cj_l : (int)P_DUMP] = Fn[tj];
-                if (it < 6) L[hrow ? P_HL + 6 * cj + pj_l : (int)P_DUMP] = Fn[tj];
-                if (it == 1 || it == 6) L[(st && root && rho < 2) ? P_MTOP + 30 * (4 + rho) + 6 + cj : (int)P_DUMP] = Fn[2 + tj];     // rows 4, 5 of the F2 column
+            for (int tj = 0; tj < 2; tj++) {
+                const bool ex = tj ? ex1 : ex0;
+                double *const f2 = ex ? L + (P_MTOP + 30 * rho + 12 + jst - q) : dump, *const f2b = (ex && rho < 2) ? L + (P_MTOP + 30 * (4 + rho) + 12 + jst - q) : dump;
+                f2[-4 * tj] = Fn[tj]; f2b[-4 * tj] = Fn[2 + tj];
             }
+        } else if (it == 1) {                                      // legs: on the way up; arm blocks: the head's root (columns 0, 1 = joints 23, 22 -> F2)
+            double *const f2 = (!leg && q < 2) ? L + (P_MTOP + 30 * rho + 6 + 23 - q) : dump, *const f2b = (!leg && q < 2 && rho < 2) ? L + (P_MTOP + 30 * (4 + rho) + 6 + 23 - q) : dump;
+            f2[0] = Fn[0]; f2b[0] = Fn[2];
+            double *const h1 = leg ? pH1[0] : dump, *const h2 = leg ? pH2[0] : dump;
+            h1[6 * d] = Fn[0]; h2[d] = Fn[0];
+        } else if (it == 0) {                                      // arm blocks: the head's leaf (joint 23) hands its column to joint 22; legs: nothing
+            double *const hh = (!leg && r2 && q == 0) ? L + (P_HL + 6 * 22 + 1) : dump;
+            hh[0] = Fn[0]; hh[5] = Fn[0];                          // H(22, 23) | H(23, 22)
+        } else {
+#pragma unroll
+            for (int tj = 0; tj < ((it >= 4) ? 2 : 1); tj++) { pH1[tj][6 * d - 4 * tj] = Fn[tj]; pH2[tj][d - 24 * tj] = Fn[tj]; }
         }
         if (it == 1 || it == 6) {                                  // park X' Ic X of the limb root for the base sum (reference order head, LA, RA, LL, RL)
-            const int slot = (it == 1) ? 0 : 4 - b;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int i = 4 * (t >> 1) + rho, j = 4 * (t & 1) + q;
-                const bool ok = active && root && i < 6 && j < 6;
-                L[ok ? A_XR + 36 * slot + (par ? 6 * i + j : 6 * j + i) : (int)P_DUMP] = Zn[t];     // M = Ic gave (X' Ic X)'
+            for (int t = 0; t < 4; t++) {                          // M = Ic gave (X' Ic X)': level 6: legs hold Ic' (offsets as stored), arms Ic (transposed); level 1 (arms): Ic'
+                double *const o = (it == 6) ? (tin[t] ? L + (A_XR + 36 * (4 - b) + (leg ? xo[t] : xt[t])) : dump) : ((tin[t] && !leg) ? L + (A_XR + xo[t]) : dump);
+                o[0] = Zn[t];
             }
         }
-        const bool keep = active && !root;
 #pragma unroll
-        for (int t = 0; t < 4; t++) { Z[t] = (it < 2) ? (keep ? Zn[t] : 0.0) : Zn[t]; F[t] = Fn[t]; }
+        for (int t = 0; t < 4; t++) { Z[t] = (it == 1) ? (leg ? Zn[t] : 0.0) : Zn[t]; F[t] = Fn[t]; }      // (the arms start afresh above the head's root)
     }
     WSYNC();
     SUBSTAMP(10);
@@ -1555,6 +1602,7 @@ __device__ __forceinline__ double jdense(const double *L, int row, int col)
 #define P_RK (P_TIME + 1)          // cached preview index (as a double; set to -2^30 when a robot is loaded)
 #define P_RPH (P_TIME + 2)         // support phase of sample k
 #define P_RXS (P_TIME + 3)         // the robot's step-length scale (lmh_set_xscale), 1 without
+#define P_ORI (P_TIME + 4)         // 1 = the feet's orientation term of the coming evaluation already sits in P_FREF (rollout: formed behind the look-ahead kinematics)
 #define P_RT0 (P_POLY + 54)        // start time of the cached swing segment (0 without segments)
 __device__ __forceinline__ void refs_prepare(double *L, LmhCParams &P, int inst, double t)
 {
@@ -1590,16 +1638,19 @@ __device__ __forceinline__ void refs_prepare(double *L, LmhCParams &P, int inst,
         const double tl = t - L[P_RT0];
 #pragma unroll
         for (int i = 0; i < 8; i++) co[i] = L[P_POLY + 24 * ft + 8 * ax + i];
-        const int n = (int)L[P_POLY + 48 + 3 * ft + ax];
-        double pv = 0, xp = 1;
+        // polyval / polyder over all eight terms: the coefficients beyond a polynomial's count are stored as zeros (lmh_set_foot_coeffs, the
+        // segment records), and a zero coefficient adds an exact zero -- no count, no selects; the powers of t are formed once
+        double pw[8];
+        pw[0] = 1.0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (i < n) { pv += co[i] * xp; xp *= tl; }
-        double vv = 0; xp = 1;
+        for (int i = 1; i < 8; i++) pw[i] = pw[i - 1] * tl;
+        double pv = 0, vv = 0, av = 0;
 #pragma unroll
-        for (int i = 0; i < 7; i++) if (i < n - 1) { vv += ((i + 1) * co[i + 1]) * xp; xp *= tl; }
-        double av = 0; xp = 1;
+        for (int i = 0; i < 8; i++) pv += co[i] * pw[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) if (i < n - 2) { av += ((i + 1) * ((i + 2) * co[i + 2])) * xp; xp *= tl; }
+        for (int i = 0; i < 7; i++) vv += ((i + 1) * co[i + 1]) * pw[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) av += ((i + 1) * ((i + 2) * co[i + 2])) * pw[i];
         double *pr = L + P_PRE + 4 + 3 * (3 * ft + ax);
         pr[0] = pv; pr[1] = vv; pr[2] = av;
     }
@@ -1720,15 +1771,22 @@ __device__ __forceinline__ void refs_pd_momentum(double *L, LmhCParams &P, doubl
         L[P_HREF + lane] = P.kd_mom * (0.0 - L[P_ANGM + lane]);
     }
 }
-__device__ __forceinline__ void refs_pd_feet(double *L, LmhCParams &P, int inst, double t, int k)
+// PDFeetAcc, orientation part (controller.cpp:344-353): kp_feet * (-R_des log(R_des' R_foot)) of both feet into P_FREF[6 ft + 0..2].  It needs
+// the soles' world transforms only (T7 at Ts, T14 at Ts + stride), not the Jacobian: in single support / flight the rollout's helper wave
+// forms it behind the look-ahead kinematics (acos + sin: ~200 instructions off wave 0's path where wave 0 is the long one); in double
+// support wave 0 keeps it -- measured: the helper's instructions cost more than wave 0's (wave 0 has issue priority on the SIMD the two
+// waves of DIFFERENT robots share), so work moves to the helper only where it has real slack.
+__device__ __forceinline__ void refs_feet_orientation(double *L, LmhCParams &P, const double *Ts, int stride)
 {
     const int lane = LANE;
-    if (lane >= 8 && lane < 10) {                                  // orientation error, controller.cpp:344-353
+    if (lane >= 8 && lane < 10) {
         const int ft = lane - 8;
-        const double *T = L + P_TB + 12 * (1 + ft);
+        const double *T = Ts + stride * ft;
+        // err = R_des' R_foot with R_des = Rf_q0_ = [0 0 1; 0 -1 0; 1 0 0] (Robot.cpp:28-31) written out: row 0 = row 2 of R_foot, row 1 = -row 1,
+        // row 2 = row 0 (the products with the literal 0 / 1 / -1 entries and the sums with the resulting zeros are exact, so this is what
+        // the general 3 x 3 product returns -- without nine constants held in scalar registers across the evaluation)
         double err[9];
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) err[3 * a + b] = c_rdes[a] * T[b] + c_rdes[3 + a] * T[4 + b] + c_rdes[6 + a] * T[8 + b];
+        for (int b = 0; b < 3; b++) { err[b] = T[8 + b]; err[3 + b] = -T[4 + b]; err[6 + b] = T[b]; }
         const double tr = err[0] + err[4] + err[8];
         const double cc = fmax(-1.0, fmin(1.0, (tr - 1.0) / 2.0));
         const double phi = acos(cc);
@@ -1738,11 +1796,25 @@ __device__ __forceinline__ void refs_pd_feet(double *L, LmhCParams &P, int inst,
         (void)cphi;
         const double sc = (phi < 1e-6) ? 0.5 : (phi / (2.0 * sphi));
         const double r0 = sc * v0, r1 = sc * v1, r2 = sc * v2;
-        for (int a = 0; a < 3; a++) {
-            const double e = -(c_rdes[3 * a] * r0 + c_rdes[3 * a + 1] * r1 + c_rdes[3 * a + 2] * r2);
-            L[P_FREF + 6 * ft + a] = P.kp_feet * e + P.kd_feet * (0.0 - L[P_VFOOT + 6 * ft + a]) + 0.0;
-        }
+        const double e3[3] = {-r2, r1, -r0};                       // -R_des (r0, r1, r2)'
+        for (int a = 0; a < 3; a++) L[P_FREF + 6 * ft + a] = P.kp_feet * e3[a];
     }
+}
+__device__ __forceinline__ void refs_feet_angular_velocity_term(double *L, LmhCParams &P)     // P_FREF[angular] += kd (0 - omega_foot)
+{
+    const int lane = LANE;
+    if (lane >= 8 && lane < 14) {
+        const int i6 = lane - 8, ft = (i6 >= 3) ? 1 : 0, a = i6 - 3 * ft;
+        L[P_FREF + 6 * ft + a] = fma(P.kd_feet, 0.0 - L[P_VFOOT + 6 * ft + a], L[P_FREF + 6 * ft + a]);
+    }
+}
+// ORI_MAYBE (rollout): the helper wave may have left the orientation term in P_FREF already (L[P_ORI], see lmh_rollout_kernel)
+template <bool ORI_MAYBE = false>
+__device__ __forceinline__ void refs_pd_feet(double *L, LmhCParams &P, int inst, double t, int k)
+{
+    const int lane = LANE;
+    if (!ORI_MAYBE || __builtin_amdgcn_readfirstlane((int)L[P_ORI]) == 0) { refs_feet_orientation(L, P, L + P_TB + 12, 12); WSYNC(); }
+    refs_feet_angular_velocity_term(L, P);
     if (lane >= 16 && lane < 22) {                                 // position part, polynomials (polyval/polyder)
         const int ft = (lane - 16) / 3, ax = (lane - 16) % 3;
         const double *pr = L + P_PRE + 4 + 3 * (3 * ft + ax);     // refs_prepare
@@ -1753,7 +1825,7 @@ __device__ __forceinline__ void refs_pd_feet(double *L, LmhCParams &P, int inst,
     }
 }
 
-template <int NW>
+template <int NW, bool ORI_MAYBE = false>
 __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, double t, int wid, int *k_out, int *phase_out, bool ang)
 {
     int flags = 0;
@@ -1775,7 +1847,7 @@ __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, do
         WSYNC();
         SUBSTAMP(14);
         refs_pd_momentum(L, P, mass, zcom);
-        refs_pd_feet(L, P, inst, t, k);
+        refs_pd_feet<false>(L, P, inst, t, k);
         WSYNC();
     } else if (wid == 1) {                                         // chain A
         WSTAMP(66);
@@ -1791,7 +1863,7 @@ __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, do
         WSTAMP(67);
         refs_vfoot_pdjoints(L, P);
         WSYNC();
-        refs_pd_feet(L, P, inst, t, k);
+        refs_pd_feet<ORI_MAYBE>(L, P, inst, t, k);
         WSYNC();
     }
     return flags;
@@ -1991,6 +2063,123 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double eps,
     }
     *z_out = zj;
     *lam_out = (lane < 32 && !((F >> lane) & 1u)) ? s - L[P_QV + r] : 0.0;
+    return bad;
+}
+
+// ---- thin free sets (|F| <= 8: a foot pressing on an edge or a corner of its support polygon -- the usual case in single support), the
+// whole restricted solve in registers.  Lane r < |F| owns the r-th free coefficient i(r); with u_r = W' g_i(r) (the rows of W that belong to
+// the coefficient's foot) the entries of its row are P_rc = u_r . g_i(c) + eps [r = c], formed in a scalar loop over the set bits of F
+// (g_i(c) is read at a wave-uniform address) straight into the registers of the LDL' -- no image of P in LDS.  The multipliers of the
+// coefficients outside F come through the wrench: w = G_F z and W w by DPP row broadcasts on lanes 0..11 (z sits in lanes 0..7 of the same
+// 16-lane row), then lam_j = g_j . (W w - h) of the coefficient's foot: one LDS hand-over instead of four.
+// Returns like solve_free_set: z_j for lane j in F (0 otherwise), lam_j for lanes j < 32 outside F.
+#define LMH_DPP1(k) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf"
+template <int C>
+__device__ __forceinline__ void dpp_fmac_lane(double &acc, double src, double m)     // acc += lane_C(src) * m   (C < 16, own 16-lane row)
+{
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
+}
+// MODE 0: every free coefficient belongs to the right foot, 1: to the left foot (single support: the usual thin set), 2: mixed
+template <int C, int MODE>
+__device__ __forceinline__ void thin_cols(double *L, int nF, int (&idx)[8], const double (&uR)[6], const double (&uL)[6], double (&a)[8])
+{
+    if constexpr (C < 8) {
+        if (C < nF) {                                              // wave-uniform
+            const double *g = L + P_GCOL + 6 * (idx[C] & 15);
+            double sacc = 0.0;
+            if (MODE == 1 || (MODE == 2 && (idx[C] >> 4))) {
+#pragma unroll
+                for (int b = 0; b < 6; b++) sacc += uL[b] * g[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 6; b++) sacc += uR[b] * g[b];
+            }
+            a[C] = sacc;
+        } else a[C] = 0.0;
+        thin_cols<C + 1, MODE>(L, nF, idx, uR, uL, a);
+    }
+}
+template <int C>
+__device__ __forceinline__ void thin_wrench(double *L, int nF, int (&idx)[8], double z, int kk, bool leftlane, double &wz)
+{
+    if constexpr (C < 8) {
+        if (C < nF) {                                              // wave-uniform
+            const bool match = ((idx[C] >> 4) != 0) == leftlane;   // the coefficient pushes on this lane's foot
+            const double gv = L[P_GCOL + 6 * (idx[C] & 15) + kk];  // (no zero slot of the set-up scratch survives the cone phase: select on the value)
+            dpp_fmac_lane<C>(wz, z, match ? gv : 0.0);
+        }
+        thin_wrench<C + 1>(L, nF, idx, z, kk, leftlane, wz);
+    }
+}
+__device__ __forceinline__ int solve_free_set_thin(double *L, unsigned F_in, double eps, double *z_out, double *lam_out)
+{
+    const int lane = LANE;
+    const unsigned F = (unsigned)__builtin_amdgcn_readfirstlane((int)F_in);       // wave-uniform by construction (ballots); make it a scalar
+    const int nF = __popc(F);
+    int idx[8], ia = 0;
+    {
+        unsigned m = F;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {                              // scalar bit scan; lane c learns its coefficient through one v_writelane
+            idx[c] = __builtin_amdgcn_readfirstlane(m ? __builtin_ctz(m) : 0);        // (a scalar register whatever the compiler thinks of F)
+            m &= m - 1u;
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(ia) : "s"(idx[c]), "n"(c));
+        }
+    }
+    double uR[6] = {0, 0, 0, 0, 0, 0}, uL[6] = {0, 0, 0, 0, 0, 0};
+    {
+        const double *gi = L + P_GCOL + 6 * (ia & 15), *Wr = L + P_W + 72 * (ia >> 4);
+        double g[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) g[a] = gi[a];
+        if (F & 0xFFFFu) {                                         // wave-uniform: some right-foot coefficient is free
+#pragma unroll
+            for (int b = 0; b < 6; b++) { double sr = 0.0; for (int a = 0; a < 6; a++) sr += g[a] * Wr[12 * a + b]; uR[b] = sr; }
+        }
+        if (F >> 16) {
+#pragma unroll
+            for (int b = 0; b < 6; b++) { double sl = 0.0; for (int a = 0; a < 6; a++) sl += g[a] * Wr[12 * a + 6 + b]; uL[b] = sl; }
+        }
+    }
+    double a[8], b[1];
+    if ((F >> 16) == 0u) thin_cols<0, 0>(L, nF, idx, uR, uL, a);     // wave-uniform three-way: no per-column choice between u_R and u_L in the usual cases
+    else if ((F & 0xFFFFu) == 0u) thin_cols<0, 1>(L, nF, idx, uR, uL, a);
+    else thin_cols<0, 2>(L, nF, idx, uR, uL, a);
+    b[0] = L[P_QV + ia];
+    const int bad = ldl_solve_regs<8, 1>(a, b, (1u << nF) - 1u, L + C_LS, eps);     // + eps I: added where the pivots are read
+    const double z = (lane < nF) ? b[0] : 0.0;                     // z_r in lane r; lanes 8..15 of the row must read as zeros below
+    // w = G_F z (lanes 0..11: component kk of foot lane / 6), y = W w, r = y - h
+    const int l12 = (lane < 12) ? lane : 0;
+    const bool leftlane = l12 >= 6;
+    const int kk = l12 - (leftlane ? 6 : 0);
+    double wz = 0.0;
+    thin_wrench<0>(L, nF, idx, z, kk, leftlane, wz);
+    L[(lane < 12) ? P_W12 + lane : (int)P_DUMP] = wz;              // the wrench G c itself: if this set is accepted the recovery starts from it (cone_qp: w_done)
+    double y = -L[P_H12 + l12];
+    {
+        const double *Wk = L + P_W + 12 * l12;
+        double wr[12];
+#pragma unroll
+        for (int m2 = 0; m2 < 12; m2++) wr[m2] = Wk[m2];
+        dpp_fmac_lane<0>(y, wz, wr[0]); dpp_fmac_lane<1>(y, wz, wr[1]); dpp_fmac_lane<2>(y, wz, wr[2]); dpp_fmac_lane<3>(y, wz, wr[3]);
+        dpp_fmac_lane<4>(y, wz, wr[4]); dpp_fmac_lane<5>(y, wz, wr[5]); dpp_fmac_lane<6>(y, wz, wr[6]); dpp_fmac_lane<7>(y, wz, wr[7]);
+        dpp_fmac_lane<8>(y, wz, wr[8]); dpp_fmac_lane<9>(y, wz, wr[9]); dpp_fmac_lane<10>(y, wz, wr[10]); dpp_fmac_lane<11>(y, wz, wr[11]);
+    }
+    WSYNC();                                                       // (the L rows parked by the solve are dead)
+    L[(lane < 12) ? C_LS + lane : C_LS + 16 + (lane & 15)] = y;    // r = W w - h
+    const int pos = __popc(F & ((1u << (lane & 31)) - 1u));
+    const double zr = __shfl(z, pos & 7, 64);                      // coefficient j <- row pos(j)
+    const bool inF = (lane < 32) && ((F >> lane) & 1u);
+    const double zj = inF ? zr : 0.0;
+    WSYNC();
+    double sj = 0.0;
+    {
+        const double *g = L + P_GCOL + 6 * (lane & 15), *rr = L + C_LS + 6 * ((lane >> 4) & 1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) sj += g[k] * rr[k];
+    }
+    *z_out = zj;
+    *lam_out = (lane < 32 && !inF) ? sj : 0.0;
     return bad;
 }
 
@@ -2421,6 +2610,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
         double zj;
         if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
         double sj;
+        bool w_thin = false;                                       // this round's solve left the wrench G z in P_W12
         const int have_ki = F32 ? 0 : __builtin_amdgcn_readfirstlane((F == (unsigned)L[P_KF + 1]) ? (int)L[P_KF + 2] : 0);   // prepared by the helper wave for the warm-start set
         double tolm = toll;                                        // dual sign test of this round
         bool pt;
@@ -2439,8 +2629,21 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
             }
         } else {
             if constexpr (F32) flags |= LMH_FLAG_QP_FP64_ROUTE;    // rank-deficient contact set (or the Lawson-Hanson pass): fp64 general route
-            build_cone_rows(L, F, P.eps_coeff);                    // P_FF only (the multipliers go through the wrench G z)
-            if (solve_free_set(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+#ifdef LMH_NO_THIN                                                  // experiment switch: the general route for every set
+            if (false) {
+#else
+            if (__builtin_amdgcn_readfirstlane(__popc(F)) <= 8) {  // thin set (wave-uniform): everything in registers
+#endif
+                WSTAMP(80);
+                if (solve_free_set_thin(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+                w_thin = true;
+                WSTAMP(81);
+            } else {
+                WSTAMP(82);
+                build_cone_rows(L, F, P.eps_coeff);                // P_FF only (the multipliers go through the wrench G z)
+                if (solve_free_set(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+                WSTAMP(83);
+            }
         }
         if (dbgp && lane == 0 && it <= 12) { dbgp[4021 + 2 * it] = (double)clock64(); dbgp[4050 + it] = (double)__popc(F); }
         const bool inF = (lane < 32) && ((F >> lane) & 1u);
@@ -2451,7 +2654,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
             const unsigned bad = (unsigned)__ballot(isbad);
             if (dbgp && lane == 0 && it <= 12) { dbgp[3960 + it] = (double)F; dbgp[3975 + it] = (double)bad; }   // round trace (diagnostics)
             cj = zj;
-            if (bad == 0u) break;
+            if (bad == 0u) { if (!F32 && w_thin) *w_done = 1; break; }
             if (it >= bpp_max) { lh = true; F = 0u; cj = 0.0; continue; }    // next solve: F empty, lam = -qv
             const int nb = __popc(bad);
             if (nb < ninf) { ninf = nb; budget = 3; F ^= bad; }
@@ -2594,6 +2797,35 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
         if (lane >= 32) L[Q_ZERO + lane - 32] = 0.0;
         if (lane >= 16 && lane < 24) L[Q_TT + 18 * (lane - 16) + 15] = 0.0;     // k = 15 padding of the right-hand sides
     }
+    if (NW == 2 && wid == 1) {
+        // q = D^-1 U' Om beta and with it row 7 of bp'' (the g column of V), already HERE on the two-wave schedule: the helper used to wait ~0.8k
+        // cycles at the join below and then made wave 0 wait ~0.7k at the next one, behind this step (profiles/r04_barrier_share_mid2.txt).
+        // It forms Om beta itself -- the same expressions wave 0 evaluates for Q_OB beside it -- in lane r of every 16-lane row and feeds it to
+        // the column sums through DPP row broadcasts, so nothing has to come back through LDS: q_i = sum_r lane_r(Om beta) U[r][i].
+        WSYNC();                                                   // its own rows 12..14 of U
+        const int l16 = lane & 15;
+        const bool in = l16 < nU;
+        const int rr = (l16 < 12) ? 6 + l16 : in ? 3 + (l16 - 12) : 3;          // row of [AG ; J] behind operand row l16
+        const int r3 = (rr < 6) ? rr - 3 : 0, rj = (rr >= 6) ? rr - 6 : 0;
+        const double *T0 = L + P_TB, *cg = L + P_CG;
+        const double agp = T0[4 * r3] * cg[3] + T0[4 * r3 + 1] * cg[4] + T0[4 * r3 + 2] * cg[5];     // AGpqp, linear rows (refs_agpqp)
+        const double bj = L[P_JPQP + rj] - L[P_FREF + rj];
+        const double beta = (rr < 6) ? agp - L[P_HREF + rr] : bj;
+        const double ob = in ? ((rr < 6) ? P.w_com_lin : P.w_foot) * beta : 0.0;
+        const int ci = lane & 31;
+        const double *ucol = L + (Q_U + ci);
+        double ur[nU];
+#pragma unroll
+        for (int r = 0; r < nU; r++) ur[r] = ucol[34 * r];
+        double q = 0.0;
+        dpp_fmac_lane<0>(q, ob, ur[0]); dpp_fmac_lane<1>(q, ob, ur[1]); dpp_fmac_lane<2>(q, ob, ur[2]); dpp_fmac_lane<3>(q, ob, ur[3]);
+        dpp_fmac_lane<4>(q, ob, ur[4]); dpp_fmac_lane<5>(q, ob, ur[5]); dpp_fmac_lane<6>(q, ob, ur[6]); dpp_fmac_lane<7>(q, ob, ur[7]);
+        dpp_fmac_lane<8>(q, ob, ur[8]); dpp_fmac_lane<9>(q, ob, ur[9]); dpp_fmac_lane<10>(q, ob, ur[10]); dpp_fmac_lane<11>(q, ob, ur[11]);
+        dpp_fmac_lane<12>(q, ob, ur[12]); dpp_fmac_lane<13>(q, ob, ur[13]); dpp_fmac_lane<14>(q, ob, ur[14]);
+        const double iDi = (ci < 3) ? idp : (ci < 6) ? ida : idj;
+        const double qr = -L[P_QREF + ((ci < 30) ? ci : 0)];
+        L[Q_BPT + 34 * 7 + ci] = (ci < 30) ? qr + q * iDi : 0.0;   // (lanes 32..63 repeat lanes 0..31)
+    }
     WSTAMP(10);
     bsync<NW>();
     WSTAMP(11);
@@ -2602,6 +2834,7 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
     const double *u_row = L + Q_U + 34 * tr + tq;                  // A fragment of U (row tr < 16: row 15 is zero)
     // ---- Cm = Om^-1 + U D^-1 U'  (wave 0)  |  q, then V = U [bp'_g + q | bp'_M]  (helper wave)
     if (NW == 1 || wid == 1) {
+        if constexpr (NW == 1) {
         if (lane < 32) {                                           // q_i = D^-1_i sum_r U[r][i] (Om beta)_r ; row 7 of bp'' = -qref + q
             double q = 0.0;
 #pragma unroll
@@ -2610,6 +2843,7 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
             L[Q_BPT + 34 * 7 + lane] = L[Q_BPT + lane] + q * iDi;  // columns 30, 31: 0 + 0
         }
         WSYNC();
+        }
         const double *b_row = (tr == 0) ? L + Q_BPT + 34 * 7 + tq : (tr < 7) ? L + Q_BPT + 34 * tr + tq : zero;
         const v4d vv = mfma_ptr<8, 4, 4>(u_row, b_row);
 #pragma unroll
@@ -2656,7 +2890,7 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
             L[(m < 6) ? Q_Z + 18 * m + tr : Q_TRASH + lane] = zz[g];
             L[(m < 6 && tr < 8) ? Q_MBP + 8 * m + tr : Q_TRASH + lane] = mb[g];
         }
-        if constexpr (NW == 2) slack(0);
+        if constexpr (NW == 2) slack(0);                           // (the helper waits ~1.7k cycles at this join otherwise: profiles/r04_barrier_share_mid2.txt)
     }
     bsync<NW>();
     WSTAMP(16);
@@ -2677,6 +2911,8 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
             }
         }
         WSTAMP(17);
+        // K_f^-1 of the warm-start set (rollout; usually nothing to do: the set has not moved): behind the Y tiles, beside wave 0's chain S .. qv
+        if constexpr (NW == 2) slack(1);
     }
     // ---- wave 0: S | d = Mb bp' - Z t''  ->  S^-1  ->  T1 = Jb S^-1  ->  [W | h]  ->  qv
     if (NW == 1 || wid == 0) {
@@ -3006,11 +3242,12 @@ __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wi
     } else {
     // helper wave, PIPE: K_f^-1 (scratch S0 + [2300, 2480): above every array of the set-up), then the part of the look-ahead that needs no
     // scratch; where the helper has slack (qp_setup15), else at the end of its share
-    auto slack = [&](int) { if constexpr (PIPE) { kinv_prework(L, P); window(0); } };
+    // slack(0): its own RK4 stage, beside wave 0's 15 x 15 solve; slack(1): K_f^-1 of the warm-start set if it moved, behind the Y tiles
+    auto slack = [&](int part) { if constexpr (PIPE) { if (part == 0) window(0); else kinv_prework(L, P); } };
     if (P.w_com_ang == 0.0) flags = qp_setup15<NW, decltype(slack)>(L, P, wid, dbgp, slack);
     else {
         flags = qp_setup<18, NW>(L, P, wid, dbgp);
-        if (NW == 2 && wid == 1) slack(0);
+        if (NW == 2 && wid == 1) { slack(0); slack(1); }
     }
     WSTAMP(18);
     bsync<NW>();                                                   // Y (helper wave) is complete; the cone solve may overwrite the set-up scratch
@@ -3340,7 +3577,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     WSTAMP(6);
     STAMP(6);
     const bool ang = (P.w_com_ang != 0.0) || (dbg != nullptr);     // angular-momentum rows: only when weighted (or dumped)
-    flags |= phase_refs<NW>(L, P, inst, t, wid, k_out, &ph, ang);
+    flags |= phase_refs<NW, PIPE>(L, P, inst, t, wid, k_out, &ph, ang);        // PIPE: the feet's orientation term may have been formed behind the look-ahead kinematics
     if (NW == 2 && wid == 0 && P.w_com_ang == 0.0 && !QF32) { WSTAMP(68); qp_prefill15(L, P); }      // ahead of the join: wave 1's chain is the longer one
     WSTAMP(7);
     bsync<NW>();
@@ -3454,7 +3691,7 @@ __global__ void __launch_bounds__(64 * NW) lmh_eval_kernel(LmhDevParams P_arg, d
         for (int e = LANE; e < 91; e += 64) L[P_Q + e] = st[e];    // q | v | v_prev | t
         F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
         F = P.warm_start ? ~F : 0xFFFFFFFFu;                       // status keeps the ACTIVE mask
-        if (LANE == 0) { L[P_KF] = (double)F; L[P_KF + 2] = 0.0; }             // no K_f^-1 stored yet
+        if (LANE == 0) { L[P_KF] = (double)F; L[P_KF + 2] = 0.0; L[P_ORI] = 0.0; }             // no K_f^-1 stored yet, no orientation term formed ahead
         WSYNC();
     }
     bsync<NW>();
@@ -3616,7 +3853,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
         if (lane < 30) L[P_VP + lane] = st[60 + lane];
         F = (unsigned)status[LMH_STATUS_STRIDE * inst + 3];
         F = P.warm_start ? ~F : 0xFFFFFFFFu;
-        if (lane == 0) { L[P_KF] = (double)F; L[P_KF + 2] = 0.0; }             // no K_f^-1 stored yet
+        if (lane == 0) { L[P_KF] = (double)F; L[P_KF + 2] = 0.0; L[P_ORI] = 0.0; }             // no K_f^-1 stored yet, no orientation term formed ahead
         if constexpr (PIPE) {
             if (lane < 60) L[P_Q + lane] = x;
             WSYNC();
@@ -3666,6 +3903,14 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
                     if (tn != ts) refs_prepare(L, *Pe, inst, tn);
                     WSTAMP(62);
                     phase_fk<R, true>(L, Pe->gcol + 228, (R)xs, xd4n);
+                    {   // the feet's orientation term of that evaluation (acos + sin, ~250 instructions; P_FREF is dead since the QP fills): here when
+                        // the coming evaluation is in single support or flight -- wave 0's share behind this join (general-route cone solve) is
+                        // then much the longer one (the helper waited ~9.6k cycles here, profiles/r04_barrier_share_mid.txt); in double support the
+                        // two shares are level and wave 0 keeps the term (refs_pd_feet)
+                        const bool ori = __builtin_amdgcn_readfirstlane((int)L[P_RPH]) != LMH_PHASE_DOUBLE;
+                        if (ori) refs_feet_orientation(L, *Pe, L + A_T + 84, 84);
+                        if (lane == 0) L[P_ORI] = ori ? 1.0 : 0.0;
+                    }
                     WSTAMP(70);
                 }
             };

@@ -32,7 +32,7 @@ names = {0: "eval start", 1: "fk / prep done", 2: "joined", 3: "com_x share", 4:
          30: "cone entry", 31: "qmax", 32: "12x12 rows", 33: "12x12 solve", 34: "c = Gpinv u", 35: "feasible?", 40: "ldl start", 41: "ldl fwd", 42: "ldl park", 43: "ldl back",
          44: "fk: sincos", 45: "fk: local T", 46: "com", 47: "E, p", 48: "B", 49: "NE fwd sweep", 50: "NE body forces", 51: "NE bwd sweep", 52: "crba levels",
          60: "w1 rk4 stage", 61: "ahead: refs", 62: "ahead: fk", 63: "kinv prework", 64: "jacobian", 66: "refs A (w1)", 67: "refs B (w0)", 68: "prefill15",
-         69: "w1 rk4 done", 70: "ahead done", 71: "eval done", 72: "stage end"}
+         69: "w1 rk4 done", 70: "ahead done", 71: "eval done", 72: "stage end", 80: "cone: thin solve", 81: "cone: thin done", 82: "cone: general solve", 83: "cone: general done"}
 CLS = ["f64", "mfma", "sel", "lane", "mov", "int", "cmp", "cvt", "oth"]
 
 

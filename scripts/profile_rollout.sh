@@ -3,7 +3,7 @@
 # Counters are collected in their own passes (never combined with a trace domain).  Output: gpurun_out/prof_$1/
 # then summarised by scripts/summarise_profile.py into profiles/.   Usage: profile_rollout.sh TAG [bench.py args, e.g. --config 2]
 set -e
-TAG=${1:-r03_c3}
+TAG=${1:-r04_c3}
 shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
