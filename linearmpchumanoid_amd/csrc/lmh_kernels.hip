@@ -988,16 +988,13 @@ __device__ __forceinline__ void phase_com_x(LV<R> L, int wid)
             const int e = (lane < 9) ? lane : (lane < 12) ? 0 : lane - 12, a0 = e / 3, b0 = e % 3;
             L[P_X0 + lane] = (lane < 9) ? L[A_XF + 6 * b0 + a0] : (lane < 12) ? L[A_XP + lane - 9] : L[A_XF + 6 * (3 + a0) + b0];
         }
-        // base-frame reordered velocities, stale (Robot::v_) and fresh: swapBaseVelocityAndRefToWorldFrame
-        if (lane < 60) {
-            const int which = lane / 30, i = lane % 30;
-            const LV<R> v = L + (which ? P_V : P_VP);
-            R val;
-            if (i < 6) {
-                const LV<R> X = L + A_XF + 6 * i;                  // row i of X_0
-                val = ((R)X[0] * (R)v[3] + (R)X[1] * (R)v[4] + (R)X[2] * (R)v[5]) + ((R)X[3] * (R)v[0] + (R)X[4] * (R)v[1] + (R)X[5] * (R)v[2]);
-            } else val = v[i];
-            L[(which ? P_VHN : P_VHS) + i] = val;
+        // base-frame reordered velocities, stale (Robot::v_: lanes 0..29) and fresh (lanes 32..61): swapBaseVelocityAndRefToWorldFrame
+        {
+            const int which = lane >> 5, i = lane & 31, ic = (i < 30) ? i : 29, i6 = (i < 6) ? i : 0;
+            const LV<R> v = L + (which ? P_V : P_VP), X = L + A_XF + 6 * i6;              // row i of X_0
+            const R dot = ((R)X[0] * (R)v[3] + (R)X[1] * (R)v[4] + (R)X[2] * (R)v[5]) + ((R)X[3] * (R)v[0] + (R)X[4] * (R)v[1] + (R)X[5] * (R)v[2]);
+            const R cpy = v[ic];
+            L[(which ? P_VHN : P_VHS) + ic] = (i < 6) ? dot : cpy;     // (lanes 30, 31 / 62, 63 repeat entry 29)
         }
     }
     WSYNC();
@@ -3757,30 +3754,36 @@ __device__ __forceinline__ int rollout_claim(int *ticket, int n_inst, long long 
 template <int XDQ = 0>
 __device__ __forceinline__ void rk4_stage(double *L, int stage, int lane, double dt, int xd4, double &x, double &ksum, double &xs)
 {
-    double xd = 0.0;
-    if (XDQ == 2 && lane < 60) xd = (lane >= 30) ? L[P_QDD + lane - 30] : L[P_XDQ + lane];
-    else if (lane < 60) {
-        if (lane >= 30) xd = L[P_QDD + lane - 30];
-        else if (lane >= 6) xd = L[P_V + lane];
-        else if (lane < 3) {
-            const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
-            const double p0 = L[P_Q], p1 = L[P_Q + 1], p2 = L[P_Q + 2];
-            const double cr = (lane == 0) ? (-w2 * p1 + w1 * p2) : (lane == 1) ? (w2 * p0 - w0 * p2) : (-w1 * p0 + w0 * p1);
-            xd = L[P_V + lane] + cr;                               // v_classic = v_spatial + w x p
-        } else {
-            const double sp = L[xd4], cp = L[xd4 + 1], sy = L[xd4 + 2], cy = L[xd4 + 3];
-            const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
-            const double tp = sp / cp;
-            xd = (lane == 3) ? (cy / cp) * w0 + (sy / cp) * w1 + 0.0 * w2
-               : (lane == 4) ? (-sy) * w0 + cy * w1 + 0.0 * w2
-                             : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
-        }
+    // branch-free: every lane loads from a valid address and forms the few products of the base rows, the lane's class picks the result
+    // (the lane-class branches and the four-way stage switch were ~100 scalar instructions per call)
+    double xd;
+    const int l60 = (lane < 60) ? lane : 0;
+    if constexpr (XDQ == 2) xd = L[(l60 >= 30) ? P_QDD + l60 - 30 : P_XDQ + l60];
+    else {
+        const int l30 = (l60 < 30) ? l60 : 0;
+        const double vq = L[(l60 >= 30) ? P_QDD + l60 - 30 : P_V + l60];       // joint rates | accelerations: xdot as it stands
+        const double w0 = L[P_V + 3], w1 = L[P_V + 4], w2 = L[P_V + 5];
+        const double p0 = L[P_Q], p1 = L[P_Q + 1], p2 = L[P_Q + 2];
+        const double sp = L[xd4], cp = L[xd4 + 1], sy = L[xd4 + 2], cy = L[xd4 + 3];
+        // v_classic = v_spatial + w x p (apps/offline/main.cpp:107-112)
+        const double cr = (l30 == 0) ? (-w2 * p1 + w1 * p2) : (l30 == 1) ? (w2 * p0 - w0 * p2) : (-w1 * p0 + w0 * p1);
+        // matrixAngularVelToEulerDot (generalizedFunctions.cpp:43-50): one reciprocal of cos(pitch) (rcp + two Newton steps, full fp64)
+        // serves the three quotients -- each was a ~13-instruction IEEE division on the helper's path beside wave 0's 15 x 15 solve
+        const double icp = fast_rcp(cp), tp = sp * icp;
+        const double eu = (l30 == 3) ? (cy * icp) * w0 + (sy * icp) * w1 + 0.0 * w2
+                        : (l30 == 4) ? (-sy) * w0 + cy * w1 + 0.0 * w2
+                                     : (cy * tp) * w0 + (sy * tp) * w1 + 1.0 * w2;
+        xd = (l60 < 3) ? vq + cr : (l60 < 6) ? eu : vq;
+        if constexpr (XDQ == 1) L[(lane < 30) ? P_XDQ + lane : (int)P_DUMP] = xd;
     }
-    if (XDQ == 1 && lane < 30) L[P_XDQ + lane] = xd;
-    if (stage == 0) { ksum = xd; xs = x + 0.5 * dt * xd; }                              // rk4.hpp:12-17
-    else if (stage == 1) { ksum = ksum + 2.0 * xd; xs = x + 0.5 * dt * xd; }
-    else if (stage == 2) { ksum = ksum + 2.0 * xd; xs = x + dt * xd; }
-    else { ksum = ksum + xd; x = x + (dt / 6.0) * ksum; xs = x; }
+    // rk4.hpp:12-17 with the stage's coefficients as scalars: ksum <- a ksum + b xd (k1 + 2 k2 + 2 k3 + k4), x <- x + e ksum (e = dt / 6 at the
+    // fourth stage, else 0), xs <- x + c xd (c = dt / 2, dt / 2, dt, 0).  a in {0, 1} and the zero terms are exact: the same roundings as the
+    // four written-out cases
+    const double a = (stage == 0) ? 0.0 : 1.0, b = (stage == 1 || stage == 2) ? 2.0 : 1.0;
+    const double c = (stage == 3) ? 0.0 : (stage == 2) ? dt : 0.5 * dt, e = (stage == 3) ? dt / 6.0 : 0.0;
+    ksum = fma(b, xd, a * ksum);
+    x = fma(e, ksum, x);
+    xs = fma(c, xd, x);
 }
 
 // Closed loop of apps/offline/main.cpp:66-122: n_ticks x rk4Step(dynamics) with Clock::step.
@@ -3802,12 +3805,24 @@ template <typename R, bool QF32 = false>
 #endif
 #endif
 __global__ void __launch_bounds__(LMH_ROLLOUT_THREADS) LMH_ROLLOUT_ATTR
-lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket, double *state, double *out, int32_t *status, double *log, int n_ticks)
+lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket_a, double *state_a, double *out_a, int32_t *status_a, double *log_a, int n_ticks_a)
 {
     // The parameter block is read through a pointer that is made opaque once per evaluation (params_of): hoisting its ~70 scalars out
     // of the tick loop pins them in SGPRs for the whole launch (round 1: 189 SGPR + 16 VGPR spills, 60 B of scratch per lane that reached
     // HBM); re-reading them costs a few scalar-cache loads per evaluation.
     __shared__ double L[LDS_DOUBLES];
+    // The kernel's own arguments are read from the kernarg segment where they are used (a scalar load each: chunk start, chunk end, the log
+    // once per tick) instead of being carried in scalar registers across the tick loop, where they were spilled to vector lanes and read back.
+    (void)ticket_a; (void)state_a; (void)out_a; (void)status_a; (void)log_a; (void)n_ticks_a;
+    struct Args { const LmhDevParams *Pg; int *ticket; double *state, *out; int32_t *status; double *log; int n_ticks; };
+    typedef const __attribute__((address_space(4))) Args CArgs;
+    auto KA = [&]() -> CArgs & { CArgs *p_ = (CArgs *)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p_)); return *p_; };
+#define ticket (KA().ticket)
+#define state (KA().state)
+#define out (KA().out)
+#define status (KA().status)
+#define log (KA().log)
+#define n_ticks (KA().n_ticks)
     LmhCParams *Pc = (LmhCParams *)(uintptr_t)Pg;
     LmhCParams &P = *Pc;
     // One workgroup runs several robots one after the other (grid = the number of workgroups the chip holds at once, lmh_launch_rollout):
@@ -4018,6 +4033,12 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     }
     if (leave != 0 && threadIdx.x == 0) { ticket[0] = 0; ticket[1] = 0; ticket[2] = 0; __threadfence(); }
 }
+#undef ticket
+#undef state
+#undef out
+#undef status
+#undef log
+#undef n_ticks
 
 // Robot::Robot model preparation (Robot.cpp:14-22) + Dynamics::spatialInertiaMatrix pieces
 // (Dynamics.cpp:4-13): raw [28][13] -> device model record.

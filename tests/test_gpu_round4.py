@@ -158,3 +158,27 @@ def test_config2_full_amplitude_fallers_match_the_oracle_until_either_gives_up()
         for tk in range(0, 800):
             assert close(glog[tk, j, :24], ref[tk, :24]) and close(glog[tk, j, 24:], ref[tk, 24:], scale=WEIGHT), (i, tk)
         assert max(vec_err(glog[tk, j, :24], ref[tk, :24]) for tk in range(0, 800, 7)) < 1e-8
+
+
+# ------------------------------------------------------------------------------- bench.py: the evaluation-API lines
+def test_bench_eval_mode_reports_both_lines():
+    """`bench.py --mode eval` (secondary lines): (a) lmh_eval on every robot of the walking workload per launch, at a
+    double-support and a single-support state, with the HBM roofline on SURVEY 8d's 1 008 B per evaluation; (b) B = 1 through lmh_eval_host,
+    four calls per tick as the shim's Controller::standStep is driven by apps/offline/main.cpp:66-89, beside the C oracle on one core and the
+    shim-built apps/offline_stand run end to end (its CoM-x trace ends where SURVEY's anchor says: -1.34e-4)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "eval", "--instances", "512", "--steps", "30", "--warmup", "5"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["unit"] == "evaluations/s" and d["secondary_line"] is True and d["config"]["mode"] == "eval"
+    ph = d["by_support_phase"]
+    assert ph["double_support"]["support_phase"] == 0 and ph["single_support"]["support_phase"] in (1, 2)
+    assert all(v["instances_flagged"] == 0 and v["evaluations_per_s"] > 1e5 for v in ph.values())
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] == "lmh_eval_kernel" and rf["algorithmic_bytes_per_launch"] == 512 * 1008
+    assert abs(rf["achieved"] - 512 * 1008 / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    b1 = d["b1_host_path"]
+    assert 0.0 < b1["ms_per_tick"] < 50.0 and abs(b1["ms_per_evaluation"] * 4 - b1["ms_per_tick"]) < 1e-9
+    assert b1["cpu_oracle_single_core"]["cores"] == 1 and b1["cpu_oracle_single_core"]["ms_per_tick"] > 0.0
+    app = b1["offline_stand_app"]
+    assert app["returncode"] == 0 and abs(app["last_com_x"] - (-1.34198e-4)) < 1e-8
