@@ -1025,9 +1025,19 @@ __device__ __forceinline__ TreeDup tree_dup()
 // PLANT = true is the build-defined plant's own pass (lmh_config.plant): the same recursion on the CURRENT velocity (P_VHN), result
 // C(q, v) with gravity into P_VHS (the stale base-frame velocity is dead once the controller's pass has run); P_C, P_CG and P_JPQP are
 // left alone -- the controller's terms keep the reference's stale-velocity semantics.
+// ONE CHAIN in fp64 (LIN): the reference runs the recursion with and without gravity (Cg, of which only the base rows are read, and the
+// soles' Jdot qdot come from the gravity-free one).  The recursion is affine in the base acceleration: the gravity part of every body's
+// acceleration is gamma_i = X_(0->i) gamma_0 with gamma_0 = X_0 (0 0 0 0 0 9.81)', so
+//     C[0:6] - Cg[0:6] = sum_i X_(i->0)' I_i X_(0->i) gamma_0 = Ic_0 gamma_0      (Ic_0: the composite inertia the CRBA forms with the same X, I)
+//     a0_sole = ag_sole - (X_sole ... X_1) gamma_0                                 (the product is the base block of the sole's Jacobian)
+// and the gravity-free chains (6 of 18 DPP FMAs per level on the way down, 6 of 12 on the way up, half of the body forces) are not run:
+// refs_agpqp forms Cg[0:6] = C[0:6] - Ic_0 gamma_0 once the mass matrix is there, refs_jpqp the soles' accelerations behind the Jacobian.
+// The subtractions cancel ~2 digits (52 N of weight against velocity products of O(0.1..1)): 1e-14 relative in fp64, which is why the fp32
+// model-term modes (R = float) keep both chains.
 template <typename R, bool PLANT = false>
 __device__ __forceinline__ void phase_newton_euler(LV<R> L)
 {
+    constexpr bool LIN = std::is_same_v<R, double>;
     const int lane = LANE;
     constexpr int VSRC = PLANT ? (int)P_VHN : (int)P_VHS;
     constexpr int CDST = PLANT ? (int)P_VHS : (int)P_C;
@@ -1039,7 +1049,8 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
     const LV<R> Vb = L + (A_VEL + 6 * tr.fb + r), Va = L + (A_VEL + 6 * tr.fa + r);                  // A_VEL | + 168 A_ACCG | + 336 A_ACC0
     // base: vel0 = vhat[0:6]; accg0 = X0 * [0 0 0 0 0 9.81]; acc00 = 0
     const R bv = L[VSRC + r], bg = (R)L[A_XF + 6 * r + 5] * (R)9.81;
-    L[A_VEL + r] = bv; L[A_ACCG + r] = bg; L[A_ACC0 + r] = 0.0;
+    L[A_VEL + r] = bv; L[A_ACCG + r] = bg;
+    if constexpr (!LIN) L[A_ACC0 + r] = 0.0;
     {   // velocity and acceleration sweeps down the limbs, one frame per depth, recurrences in registers:
         // v_i = X_i v_p + S qd_i; a_i = X_i a_p + crm(v_i) S qd_i (with / without gravity in the base acceleration)
         const R s2 = (r == 2) ? (R)1 : (R)0;                       // S = e_z (angular): component 2
@@ -1068,9 +1079,11 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
             const R cs = (ca * dpp_row<0x101>(v) + cb * dpp_row<0x111>(v)) * qd;      // row_shl:1 (lane + 1) | row_shr:1 (lane - 1)
             R ag = cs, a0 = cs;
             bdot6(ag, pg, x);
-            if (d > 0) bdot6(a0, p0, x);                           // (the base's gravity-free acceleration is zero)
+            if (!LIN && d > 0) bdot6(a0, p0, x);                   // (the base's gravity-free acceleration is zero)
             const LV<R> O = (d < 5) ? Vb + 6 * d : Va + 6 * d;
-            O[0] = v; O[168] = ag; O[336] = a0;
+            O[0] = v; O[168] = ag;
+            if constexpr (!LIN) O[336] = a0;
+            if constexpr (LIN && !PLANT) { if (d == 6) L[tr.arms ? (int)NE_DUMP + 16 + r : P_JPQP + 6 * (tr.rho & 1) + r] = ag; }    // the soles' (refs_jpqp)
             pv = v; pg = ag; p0 = a0;
         }
     }
@@ -1079,8 +1092,8 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
     WSTAMP(49);
     // body forces f = I a + v x* (I v), one lane per (body, which)
     {
-        const bool fon = lane < 50;
-        const int which = fon ? lane / 25 : 0, i = f_body(lane % 25);
+        const bool fon = lane < (LIN ? 25 : 50);
+        const int which = (!LIN && fon) ? lane / 25 : 0, i = f_body(LIN ? (fon ? lane : 0) : lane % 25);
         const LV<R> mo = L + P_MODEL + LMH_BODY_STRIDE * i;
         const LV<R> v = L + A_VEL + 6 * i, a = L + (which ? A_ACC0 : A_ACCG) + 6 * i;
         const R m = mo[12], hx = mo[9], hy = mo[10], hz = mo[11];
@@ -1128,10 +1141,10 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
 #pragma unroll
             for (int k = 0; k < 6; k++) ws[d][k] = X[6 * k];
             const LV<R> F = (d < 5) ? Fb + 6 * d : Fa + 6 * d;
-            fgs[d] = F[0]; f0s[d] = F[168];
+            fgs[d] = F[0]; f0s[d] = LIN ? (R)0 : (R)F[168];
         }
         __builtin_amdgcn_sched_barrier(0);
-        R fg = tr.arms ? fgs[6] : (R)0, f0 = tr.arms ? f0s[6] : (R)0;          // total force of the frame at depth 6
+        R fg = tr.arms ? fgs[6] : (R)0, f0 = (!LIN && tr.arms) ? f0s[6] : (R)0;          // total force of the frame at depth 6
         Ca6[6] = fg;
 #pragma unroll
         for (int d = 6; d >= 0; d--) {
@@ -1140,18 +1153,20 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
             if (d == 0) {                                          // limb roots: X' fs parked for the base sum, slot = chain (RL, LL, RA, LA)
                 R ng = 0, n0 = 0;
                 bdot6(ng, fg, w);
-                bdot6(n0, f0, w);
-                L[A_VEL + 12 * tr.rho + r] = ng; L[A_VEL + 12 * tr.rho + 6 + r] = n0;         // A_VEL is dead after the body forces
+                if constexpr (!LIN) bdot6(n0, f0, w);
+                L[A_VEL + 12 * tr.rho + r] = ng;                   // A_VEL is dead after the body forces
+                if constexpr (!LIN) L[A_VEL + 12 * tr.rho + 6 + r] = n0;
             } else if (d == 5) {                                   // arm rows: the head's root (parked, slot 4), the arm's tip starts afresh
                 R ng = tr.arms ? (R)0 : fgs[4], n0 = tr.arms ? (R)0 : f0s[4];
                 bdot6(ng, fg, w);
-                bdot6(n0, f0, w);
-                Pk5[0] = ng; Pk5[6] = n0;
+                if constexpr (!LIN) bdot6(n0, f0, w);
+                Pk5[0] = ng;
+                if constexpr (!LIN) Pk5[6] = n0;
                 fg = tr.arms ? fgs[4] : ng; f0 = tr.arms ? f0s[4] : n0;
             } else {
                 R ng = fgs[d - 1], n0 = f0s[d - 1];
                 bdot6(ng, fg, w);
-                bdot6(n0, f0, w);
+                if constexpr (!LIN) bdot6(n0, f0, w);
                 fg = ng; f0 = n0;
             }
         }
@@ -1159,15 +1174,15 @@ __device__ __forceinline__ void phase_newton_euler(LV<R> L)
     WSYNC();
     SUBSTAMP(8);
     WSTAMP(51);
-    if (lane < 12) {                                               // base: head, LA, RA, LL, RL (Dynamics.cpp:157-162 order)
-        const int w2 = lane / 6, k2 = lane % 6;
+    if (lane < (LIN ? 6 : 12)) {                                   // base: head, LA, RA, LL, RL (Dynamics.cpp:157-162 order)
+        const int w2 = LIN ? 0 : lane / 6, k2 = LIN ? lane : lane % 6;
         R acc = L[(w2 ? A_F0 : A_FG) + k2];
 #pragma unroll
         for (int cc = 4; cc >= 0; cc--) acc += L[A_VEL + 12 * cc + 6 * w2 + k2];
         if constexpr (PLANT) { if (w2 == 0) L[P_VHS + k2] = acc; }
         else { if (w2 == 0) L[P_C + k2] = acc; else L[P_CG + k2] = acc; }
     }
-    if (!PLANT && lane >= 40 && lane < 52) {                       // Jpqp = blkdiag(R,R) acc0[sole]
+    if (!LIN && !PLANT && lane >= 40 && lane < 52) {               // Jpqp = blkdiag(R,R) acc0[sole]   (LIN: refs_jpqp, behind the Jacobian)
         const int foot = (lane - 40) / 6, k2 = (lane - 40) % 6, rr = k2 % 3, o = (k2 / 3) * 3;
         const LV<R> T = L + P_TB + 12 * (1 + foot), a = L + A_ACC0 + 6 * (foot ? 14 : 7);
         L[P_JPQP + 6 * foot + k2] = T[4 * rr] * a[o] + T[4 * rr + 1] * a[o + 1] + T[4 * rr + 2] * a[o + 2];
@@ -1513,7 +1528,14 @@ __device__ __forceinline__ void phase_crba_mfma(double *L, const IbSel &g)
 template <typename R>
 __device__ __forceinline__ void phase_crba(LV<R> L, const IbSel &g)
 {
-    if constexpr (std::is_same_v<R, double>) phase_crba_mfma(L.p, g);
+    if constexpr (std::is_same_v<R, double>) {
+        phase_crba_mfma(L.p, g);
+        // the gravity part of the bias' base rows, Ic_0 gamma_0 with gamma_0 = 9.81 (0 0 0 | third row of E0): see phase_newton_euler (ONE CHAIN)
+        const int lane = LANE, k = (lane < 6) ? lane : 0;
+        const double *m = L.p + P_MTOP + 30 * k + 3, *e2 = L.p + P_X0 + 6;
+        const double gv = 9.81 * (m[0] * e2[0] + m[1] * e2[1] + m[2] * e2[2]);
+        if (lane < 6) L.p[P_CG + lane] = gv;
+    }
     else phase_crba_rows<R>(L);
 }
 
@@ -1566,6 +1588,20 @@ __device__ __forceinline__ void phase_jacobian(LV<R> L)
 #pragma unroll
         for (int r3 = 0; r3 < 3; r3++) O[12 * r3] = T[4 * r3] * j0 + T[4 * r3 + 1] * j1 + T[4 * r3 + 2] * j2;
     }
+    WSYNC();
+}
+
+// Jpqp = blkdiag(R, R) a0_sole (controller.cpp's Jdot qdot of the soles) from the ONE Newton-Euler chain, fp64 schedule:
+// a0_sole = ag_sole - X_(0->sole) gamma_0, and blkdiag(R, R) X_(0->sole) is the base block of the rotated Jacobian (phase_jacobian).
+// phase_newton_euler has parked the soles' ag raw in P_JPQP; runs behind phase_jacobian, in place.
+__device__ __forceinline__ void refs_jpqp(double *L)
+{
+    const int lane = LANE, l12 = (lane < 12) ? lane : 0, foot = l12 / 6, k2 = l12 % 6, rr = k2 % 3, o = (k2 / 3) * 3;
+    const double *T = L + P_TB + 12 * (1 + foot) + 4 * rr, *a = L + P_JPQP + 6 * foot + o, *J = L + P_JC + 72 * foot + 12 * k2 + 3, *e2 = L + P_X0 + 6;
+    double val = T[0] * a[0] + T[1] * a[1] + T[2] * a[2];
+    val -= 9.81 * (J[0] * e2[0] + J[1] * e2[1] + J[2] * e2[2]);
+    __builtin_amdgcn_sched_barrier(0);                             // every lane has read the raw accelerations before any lane overwrites them
+    if (lane < 12) L[P_JPQP + lane] = val;
     WSYNC();
 }
 
@@ -1682,11 +1718,16 @@ __device__ __forceinline__ void refs_ag(double *L, double mass, bool ang)
 }
 // AGpqp = X1G Cg[0:6] (Dynamics.cpp:103-121): needs the mass matrix (CRBA) AND the gravity-free bias (Newton-Euler); on the two-wave
 // schedule those come from different waves, so this piece runs after their join (phase_qp), not inside the reference chains
+template <bool CGLIN>
 __device__ __forceinline__ void refs_agpqp(double *L, double mass, bool ang)
 {
     const int lane = LANE;
     if (lane < 6) {
-        const double *T0 = L + P_TB, *cg = L + P_CG;
+        // CGLIN: Cg[0:6] = C[0:6] - Ic_0 gamma_0 (see phase_newton_euler); P_CG holds Ic_0 gamma_0 (refs_cg_gravity, behind the CRBA)
+        const double *T0 = L + P_TB, *c = L + P_C, *pg = L + P_CG;
+        double cg[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cg[k] = CGLIN ? c[k] - pg[k] : pg[k];
         const int r = lane % 3;
         double val = 0.0;
         if (lane < 3) { if (ang) {
@@ -1822,7 +1863,7 @@ __device__ __forceinline__ void refs_pd_feet(double *L, LmhCParams &P, int inst,
     }
 }
 
-template <int NW, bool ORI_MAYBE = false>
+template <int NW, bool ORI_MAYBE = false, bool CGLIN = true>
 __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, double t, int wid, int *k_out, int *phase_out, bool ang)
 {
     int flags = 0;
@@ -1833,7 +1874,7 @@ __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, do
     if (k < 0 || k + P.horizon >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;    // on every wave (wave 0 reports)
     if constexpr (NW == 1) {
         refs_ag(L, mass, ang);
-        refs_agpqp(L, mass, ang);
+        refs_agpqp<CGLIN>(L, mass, ang);
         WSYNC();
         SUBSTAMP(12);
         refs_momentum(L, mass, ang);
@@ -2745,7 +2786,7 @@ __device__ __forceinline__ void qp_prefill15(double *L, LmhCParams &P)
 // NW = 2 joins: fills | Cm, q+V | solve, Z+Mbp | (S..qv), Y | -> the caller's join in front of the cone solve.
 // `slack` (rollout): called by the helper wave where it is ahead of wave 0 -- after its Z / Mb bp' tiles, while wave 0 is in the 15 x 15 solve.
 struct NoWindow { __device__ __forceinline__ void operator()(int) const {} };
-template <int NW, class SF = NoWindow>
+template <int NW, class SF = NoWindow, bool CGLIN = true>
 __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, double *dbgp, SF slack = SF())
 {
     const int lane = LANE;
@@ -2804,7 +2845,10 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
         const bool in = l16 < nU;
         const int rr = (l16 < 12) ? 6 + l16 : in ? 3 + (l16 - 12) : 3;          // row of [AG ; J] behind operand row l16
         const int r3 = (rr < 6) ? rr - 3 : 0, rj = (rr >= 6) ? rr - 6 : 0;
-        const double *T0 = L + P_TB, *cg = L + P_CG;
+        const double *T0 = L + P_TB, *cc = L + P_C, *pg = L + P_CG;
+        double cg[6];
+#pragma unroll
+        for (int k = 3; k < 6; k++) cg[k] = CGLIN ? cc[k] - pg[k] : pg[k];        // Cg[3:6] (refs_agpqp: the same expressions)
         const double agp = T0[4 * r3] * cg[3] + T0[4 * r3 + 1] * cg[4] + T0[4 * r3 + 2] * cg[5];     // AGpqp, linear rows (refs_agpqp)
         const double bj = L[P_JPQP + rj] - L[P_FREF + rj];
         const double beta = (rr < 6) ? agp - L[P_HREF + rr] : bj;
@@ -3227,12 +3271,12 @@ __device__ __forceinline__ void kinv_prework(double *L, LmhCParams &P)
 // Controller::WBC Hessian/gradient + solveQP (controller.cpp:94-132,388-479), see file header.
 // PIPE (rollout): the helper wave prepares K_f^-1 at the end of its set-up share instead of at the start of the evaluation, and spends the
 // cone solve -- wave 0 alone -- inside `window` (the next evaluation's clock references and kinematics, lmh_rollout_kernel).
-template <int NW, bool F32 = false, bool PIPE = false, class WF = NoWindow>
+template <int NW, bool F32 = false, bool PIPE = false, class WF = NoWindow, bool CGLIN = true>
 __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wid, unsigned *Fmask_io, int *iters_out, double *dbgp = nullptr, WF window = WF())
 {
     const int lane = LANE;
     int flags;
-    if (NW == 2 && wid == 0) { refs_agpqp(L, L[P_MODEL + 392], (P.w_com_ang != 0.0) || (dbgp != nullptr)); WSYNC(); }     // first point where both M (wave 1) and Cg (wave 0) exist
+    if (NW == 2 && wid == 0) { refs_agpqp<CGLIN>(L, L[P_MODEL + 392], (P.w_com_ang != 0.0) || (dbgp != nullptr)); WSYNC(); }     // first point where both M (wave 1) and Cg (wave 0) exist
     if constexpr (F32) {
         if (NW == 2 && wid != 0) { bsync<NW>(); return 0; }        // fp32 QP: one wave, the helper waits for the recovery
         flags = qp_setup_f32(L, P);
@@ -3241,7 +3285,7 @@ __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wi
     // scratch; where the helper has slack (qp_setup15), else at the end of its share
     // slack(0): its own RK4 stage, beside wave 0's 15 x 15 solve; slack(1): K_f^-1 of the warm-start set if it moved, behind the Y tiles
     auto slack = [&](int part) { if constexpr (PIPE) { if (part == 0) window(0); else kinv_prework(L, P); } };
-    if (P.w_com_ang == 0.0) flags = qp_setup15<NW, decltype(slack)>(L, P, wid, dbgp, slack);
+    if (P.w_com_ang == 0.0) flags = qp_setup15<NW, decltype(slack), CGLIN>(L, P, wid, dbgp, slack);
     else {
         flags = qp_setup<18, NW>(L, P, wid, dbgp);
         if (NW == 2 && wid == 1) { slack(0); slack(1); }
@@ -3557,6 +3601,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
         phase_crba<R>(L, ibsel);
         STAMP(5);
         phase_jacobian<R>(L);
+        if constexpr (std::is_same_v<R, double>) refs_jpqp(L);
     } else {
         if (wid == 0) {                                            // LDS regions of the three are disjoint
             phase_newton_euler<R>(L);
@@ -3564,6 +3609,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
             STAMP(4);
             WSTAMP(64);
             phase_jacobian<R>(L);
+            if constexpr (std::is_same_v<R, double>) refs_jpqp(L);
         }
         else phase_crba<R>(L, ibsel);
         STAMP(5);                                                  // per wave: end of its share of the tree phases
@@ -3574,13 +3620,13 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     WSTAMP(6);
     STAMP(6);
     const bool ang = (P.w_com_ang != 0.0) || (dbg != nullptr);     // angular-momentum rows: only when weighted (or dumped)
-    flags |= phase_refs<NW, PIPE>(L, P, inst, t, wid, k_out, &ph, ang);        // PIPE: the feet's orientation term may have been formed behind the look-ahead kinematics
+    flags |= phase_refs<NW, PIPE, std::is_same_v<R, double>>(L, P, inst, t, wid, k_out, &ph, ang);        // PIPE: the feet's orientation term may have been formed behind the look-ahead kinematics
     if (NW == 2 && wid == 0 && P.w_com_ang == 0.0 && !QF32) { WSTAMP(68); qp_prefill15(L, P); }      // ahead of the join: wave 1's chain is the longer one
     WSTAMP(7);
     bsync<NW>();
     WSTAMP(8);
     STAMP(7);
-    flags |= phase_qp<NW, QF32, PIPE, WF>(L, P, ph, wid, Fmask, iters_out, dbg, window);
+    flags |= phase_qp<NW, QF32, PIPE, WF, std::is_same_v<R, double>>(L, P, ph, wid, Fmask, iters_out, dbg, window);
     STAMP(8);
     if (plant && (NW == 1 || wid == 0)) phase_plant(L, P);         // the torques drive a plant instead of being thrown away (main.cpp:118-121)
     // need_tau (wave-uniform): the integrator never reads the torques -- the rollout asks for them at the k4 stage only (log, final record)
@@ -3591,7 +3637,7 @@ __device__ __forceinline__ int controller_eval(double *L, LmhCParams &P, int ins
     if (dbg) {
         const int lane = LANE;
         for (int e = lane; e < 30; e += 64) { dbg[924 + e] = L[P_C + e]; dbg[1643 + e] = L[P_QREF + e]; dbg[3181 + e] = L[P_A + e]; }
-        for (int e = lane; e < 6; e += 64) { dbg[954 + e] = L[P_CG + e]; dbg[1464 + e] = L[P_AGPQP + e]; dbg[1673 + e] = L[P_HREF + e]; }
+        for (int e = lane; e < 6; e += 64) { dbg[954 + e] = std::is_same_v<R, double> ? L[P_C + e] - L[P_CG + e] : L[P_CG + e]; dbg[1464 + e] = L[P_AGPQP + e]; dbg[1673 + e] = L[P_HREF + e]; }
         for (int e = lane; e < 180; e += 64) { dbg[960 + e] = L[P_MTOP + e]; dbg[1284 + e] = L[P_AG + e]; }
         for (int e = lane; e < 144; e += 64) { dbg[1140 + e] = L[P_HL + e]; dbg[1482 + e] = L[P_JC + e]; dbg[1937 + e] = L[P_W + e]; }
         for (int e = lane; e < 12; e += 64) { dbg[1470 + e] = L[P_JPQP + e]; dbg[1679 + e] = L[P_FREF + e]; dbg[2081 + e] = L[P_H12 + e]; }
@@ -3906,7 +3952,11 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             LmhCParams *Pe = Pc;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
 #ifdef LMH_SUBSTAMPS
+#ifdef LMH_DIAG_STAGE                                              // the per-join split of ONE Runge-Kutta stage's evaluations (the others land in slot 7)
+            if (lane == 0) L[D_JIDX + wid] = (stage == LMH_DIAG_STAGE) ? 0.0 : 100.0;
+#else
             if (lane == 0) L[D_JIDX + wid] = 0.0;
+#endif
 #endif
             // wave 1, once its share of the QP set-up is done: the next stage's configuration (rk4_stage, position half) and the clock-only
             // references of its time (unless it is the same instant: stages 2 | 3, and 4 | 1 of the next tick); then, while wave 0 runs the

@@ -22,7 +22,7 @@ extra = [a for a in argv if a.startswith("-D")]
 if not reuse:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DLMH_PMARK", "-DLMH_ROLLOUT_ONLY",
                            "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-disable-machine-licm", *extra, src, "-o", out],
-                          stderr=subprocess.DEVNULL)
+                          stderr=subprocess.DEVNULL if "--verbose" not in argv else None)
 lines = open(out).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z18lmh_rollout_kernelIdLb0EE"))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
