@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak = 256 CU x 64 lanes x 2 flop x 2.4 GHz
 FP64_MFMA_PEAK_TFLOPS = 78.6     # v_mfma_f64_16x16x4_f64: fp64 matrix rate = fp64 vector rate on gfx950
 MFMA_MOP_FLOP = 512              # SQ_INSTS_VALU_MFMA_MOPS_F64 unit (one 16x16x4 f64 MFMA = 2048 flop = 4 MOPS)
-PROFILE_TAGS = {3: "r03_c3", 2: "r03_c2"}   # profiles/<tag>_rollout_summary.json: PMC passes of the committed kernel on the default command
+PROFILE_TAGS = {3: "r04_c3", 2: "r04_c2"}   # profiles/<tag>_rollout_summary.json: PMC passes of the committed kernel on the default command
 HARD_FLAGS = 1 | 2 | 4 | 8 | 32  # LMH_FLAG_QP_MAXITER | NONFINITE | ZMP_RANGE | NOT_SPD | UNFINISHED; LMH_FLAG_QP_FP64_ROUTE (16) is informational
 
 # One step = `ticks` ticks in one launch.  mpc_dt: MPC sample time / reference sample period (lmh_config.mpc_dt); the preview spans

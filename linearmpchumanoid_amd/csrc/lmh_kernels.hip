@@ -634,6 +634,12 @@ __device__ __forceinline__ void dpp_fmac_self(double (&a)[N], double m)         
         asm volatile("s_nop 1\n\t" LMH_FS(0, 1, 2) : "+v"(a[C0]) : "v"(m), "n"(J));
     }
 }
+#define LMH_DPP1(k) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf"
+template <int C>
+__device__ __forceinline__ void dpp_fmac_lane(double &acc, double src, double m)     // acc += lane_C(src) * m   (C < 16, own 16-lane row)
+{
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
+}
 // one pivot, then the next.  GUARD = true: `rowon` switches a whole 16-lane DPP row off (its pivots are replaced by 1) and a pivot that is
 // not above `dmin` is replaced by 1 and reported in `bad` (kinv_compute: two feet on two DPP rows, a rank-deficient K_f is an expected
 // outcome).  GUARD = false (gj_solve_regs): every DPP row carries a copy of the system, so the pivot a lane sees is always the true one --
@@ -1690,32 +1696,11 @@ __device__ __forceinline__ void refs_prepare(double *L, LmhCParams &P, int inst,
 }
 
 // The references form two independent chains: (A) AG, AGpqp -> momentum -> MPC -> PDMomentumAcc needs the mass
-// matrix; (B) foot velocities, PDJointsAcc -> PDFeetAcc needs the Jacobian.  NW = 1 interleaves them step by
-// step in one wave; NW = 2 gives chain A to wave 1 and chain B to wave 0 (the caller joins them).
+// matrix (refs_chain_a); (B) foot velocities, PDJointsAcc -> PDFeetAcc needs the Jacobian.  NW = 1 runs them one after
+// the other in one wave; NW = 2 gives chain A to wave 1 and chain B to wave 0 (the caller joins them).
 // `ang`: also the angular-momentum rows 0..2 (AG_ang, needed only when the angular-momentum weight is set or a debug record is dumped:
 // with w_com_ang = 0 -- the reference's literal -- neither the QP nor any output reads them, and they are the expensive half: 6-term
 // entries with three divisions by the mass each)
-__device__ __forceinline__ void refs_ag(double *L, double mass, bool ang)
-{
-    const int lane = LANE;
-    const double *T0 = L + P_TB;
-    for (int e = 90 + lane; e < 180; e += 64) {                    // rows 3..5: R0 Mt_lin
-        const int a = e / 30 - 3, c = e % 30;
-        const double *Mt = L + P_MTOP + c;
-        L[P_AG + e] = T0[4 * a] * Mt[90] + T0[4 * a + 1] * Mt[120] + T0[4 * a + 2] * Mt[150];
-    }
-    if (ang) {                                                     // wave-uniform
-        for (int e = lane; e < 90; e += 64) {
-            const int r = e / 30, c = e % 30;
-            const double *Mt = L + P_MTOP + c;
-            const double p0 = L[P_MTOP + 30 * 2 + 4] / mass, p1 = L[P_MTOP + 30 * 0 + 5] / mass, p2 = L[P_MTOP + 30 * 1 + 3] / mass;
-            // U = -(R0 [p1G]x): U[r][0] = -(R[r][1] p2 - R[r][2] p1) ...
-            const double R0 = T0[4 * r], R1 = T0[4 * r + 1], R2 = T0[4 * r + 2];
-            const double u0 = -(R1 * p2 + R2 * (-p1)), u1 = -(R0 * (-p2) + R2 * p0), u2 = -(R0 * p1 + R1 * (-p0));
-            L[P_AG + e] = R0 * Mt[0] + R1 * Mt[30] + R2 * Mt[60] + u0 * Mt[90] + u1 * Mt[120] + u2 * Mt[150];
-        }
-    }
-}
 // AGpqp = X1G Cg[0:6] (Dynamics.cpp:103-121): needs the mass matrix (CRBA) AND the gravity-free bias (Newton-Euler); on the two-wave
 // schedule those come from different waves, so this piece runs after their join (phase_qp), not inside the reference chains
 template <bool CGLIN>
@@ -1739,16 +1724,6 @@ __device__ __forceinline__ void refs_agpqp(double *L, double mass, bool ang)
         L[P_AGPQP + lane] = val;                                   // the angular entries are 0 when nothing reads them (see refs_ag)
     }
 }
-__device__ __forceinline__ void refs_momentum(double *L, double mass, bool ang)
-{
-    const int lane = LANE;
-    if (lane < 6) {                                                // h = AG vhat (fresh velocity)
-        const int row = (ang || lane >= 3) ? lane : 3;             // the angular rows of AG are not formed when nothing reads them
-        double s = 0.0;
-        for (int c = 0; c < 30; c++) s += L[P_AG + 30 * row + c] * L[P_VHN + c];
-        if (lane < 3) L[P_ANGM + lane] = ang ? s : 0.0; else L[P_COMV + lane - 3] = s / mass;
-    }
-}
 __device__ __forceinline__ void refs_vfoot_pdjoints(double *L, LmhCParams &P)
 {
     const int lane = LANE;
@@ -1768,46 +1743,84 @@ __device__ __forceinline__ void refs_vfoot_pdjoints(double *L, LmhCParams &P)
         L[P_QREF + ((i < 3) ? i + 3 : (i < 6) ? i - 3 : i)] = val;
     }
 }
-__device__ __forceinline__ int refs_mpc(double *L, LmhCParams &P, int inst, int k, double *zcom_out)
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)       // wave-uniform copy of lane src_lane's value (two v_readlane_b32)
 {
-    const int lane = LANE;
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// Chain A in one piece: Dynamics::centroidalMatrixAndBias (AG, Dynamics.cpp:103-121), Robot::computeComMomentum (Robot.cpp:300-310),
+// Mpc3dLip::compute (mpcLinearPendulum.cpp:78-109: u0 = -K (Px x_k - z[k : k+N+1]); K (Px x_k - z) = x sum K Px0 + xdot sum K Px1 - sum K z,
+// the three sums do not depend on the robot state and are prepared early, refs_prepare / load_common) and PDMomentumAcc
+// (controller.cpp:310-325), without LDS round trips between them; the angular rows (`ang`: weighted or dumped, see refs_ag)
+// keep the plain form beside it.  DPP row a = row 3 + a of AG (row 3 of the wave repeats a = 2), lane l16 of it forms the entries of columns
+// l16 and l16 + 16 with the expressions of refs_ag, multiplies them with vhat and the row sums go round through row broadcasts (the order
+// of the 30-term sum differs from refs_momentum's: 1e-16 relative); the three quotients reach every lane as scalars (v_readlane), so the MPC
+// step and the PD law follow in registers.
+__device__ __forceinline__ int refs_chain_a(double *L, LmhCParams &P, int inst, int k, double mass, bool ang)
+{
+    const int lane = LANE, l16 = lane & 15, q4 = lane >> 4, a = (q4 < 3) ? q4 : 2;
+    if (ang) {                                                     // wave-uniform: rows 0..2 of AG (refs_ag)
+        const double *T0 = L + P_TB;
+        for (int e = lane; e < 90; e += 64) {
+            const int r = e / 30, c = e % 30;
+            const double *Mt = L + P_MTOP + c;
+            const double p0 = L[P_MTOP + 30 * 2 + 4] / mass, p1 = L[P_MTOP + 30 * 0 + 5] / mass, p2 = L[P_MTOP + 30 * 1 + 3] / mass;
+            const double R0 = T0[4 * r], R1 = T0[4 * r + 1], R2 = T0[4 * r + 2];
+            const double u0 = -(R1 * p2 + R2 * (-p1)), u1 = -(R0 * (-p2) + R2 * p0), u2 = -(R0 * p1 + R1 * (-p0));
+            L[P_AG + e] = R0 * Mt[0] + R1 * Mt[30] + R2 * Mt[60] + u0 * Mt[90] + u1 * Mt[120] + u2 * Mt[150];
+        }
+    }
+    const bool two = l16 < 14;
+    const int c0 = l16, c1 = two ? l16 + 16 : l16;
+    const double *T0 = L + P_TB + 4 * a, *Mt = L + P_MTOP + 90, *vh = L + P_VHN;
+    const double r0 = T0[0], r1 = T0[1], r2 = T0[2];
+    const double ag0 = r0 * Mt[c0] + r1 * Mt[30 + c0] + r2 * Mt[60 + c0];
+    const double ag1 = r0 * Mt[c1] + r1 * Mt[30 + c1] + r2 * Mt[60 + c1];
+    const double v0 = vh[c0], v1 = two ? vh[c1] : 0.0;
+    double *o = L + P_AG + 30 * (3 + a);
+    o[c0] = ag0; o[c1] = ag1;                                       // (lanes 14, 15 repeat their first entry)
+    const double part = ag0 * v0 + ag1 * v1, one = 1.0;
+    double s0 = 0.0, s1 = 0.0;
+    dpp_fmac_lane<0>(s0, part, one); dpp_fmac_lane<1>(s1, part, one); dpp_fmac_lane<2>(s0, part, one); dpp_fmac_lane<3>(s1, part, one);
+    dpp_fmac_lane<4>(s0, part, one); dpp_fmac_lane<5>(s1, part, one); dpp_fmac_lane<6>(s0, part, one); dpp_fmac_lane<7>(s1, part, one);
+    dpp_fmac_lane<8>(s0, part, one); dpp_fmac_lane<9>(s1, part, one); dpp_fmac_lane<10>(s0, part, one); dpp_fmac_lane<11>(s1, part, one);
+    dpp_fmac_lane<12>(s0, part, one); dpp_fmac_lane<13>(s1, part, one); dpp_fmac_lane<14>(s0, part, one); dpp_fmac_lane<15>(s1, part, one);
+    const double cv = (s0 + s1) / mass;                             // CoM velocity, component a, on every lane of row a
+    const double vxp = readlane_f64(cv, 0), vyp = readlane_f64(cv, 16), vzp = readlane_f64(cv, 32);
     int flags = 0;
-    // ---- MPC: u0 = -K (Px x_k - z[k : k+N+1])
     const int N = P.horizon;
     if (k < 0 || k + N >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;
     const double *mp = P.mpc + (size_t)P.mpc_stride_inst * inst;
     const double zcom = mp[3 * (N + 1)];
-    {
-        // K (Px x_k - z) = x (sum K Px0) + xdot (sum K Px1) - sum K z: the three sums do not depend on the robot state and
-        // are prepared early (refs_prepare / load_common)
-        const double cxp = L[P_COM], cyp = L[P_COM + 1], vxp = L[P_COMV], vyp = L[P_COMV + 1];
-        const double kp0 = L[P_PRE + 2], kp1 = L[P_PRE + 3];
-        const double sx = (kp0 * cxp + kp1 * vxp) - L[P_RXS] * L[P_PRE];
-        const double sy = (kp0 * cyp + kp1 * vyp) - L[P_PRE + 1];
-        const double ux = -sx, uy = -sy;
-        if (lane == 0) {
-            L[P_MPC + 0] = ux; L[P_MPC + 1] = uy;
-            L[P_MPC + 2] = P.a00 * cxp + P.a01 * vxp + P.b0 * ux;   // xRef pos, vel, acc
-            L[P_MPC + 3] = P.a10 * cxp + P.a11 * vxp + P.b1 * ux;
-            L[P_MPC + 4] = ux;
-            L[P_MPC + 5] = P.a00 * cyp + P.a01 * vyp + P.b0 * uy;
-            L[P_MPC + 6] = P.a10 * cyp + P.a11 * vyp + P.b1 * uy;
-            L[P_MPC + 7] = uy;
-        }
+    // MPC: u0 = -K (Px x_k - z[k : k+N+1]) (refs_mpc)
+    const double cxp = L[P_COM], cyp = L[P_COM + 1], czp = L[P_COM + 2];
+    const double kp0 = L[P_PRE + 2], kp1 = L[P_PRE + 3];
+    const double ux = -((kp0 * cxp + kp1 * vxp) - L[P_RXS] * L[P_PRE]);
+    const double uy = -((kp0 * cyp + kp1 * vyp) - L[P_PRE + 1]);
+    const double xp = P.a00 * cxp + P.a01 * vxp + P.b0 * ux, xv = P.a10 * cxp + P.a11 * vxp + P.b1 * ux;
+    const double yp = P.a00 * cyp + P.a01 * vyp + P.b0 * uy, yv = P.a10 * cyp + P.a11 * vyp + P.b1 * uy;
+    if (lane == 0) {
+        L[P_MPC + 0] = ux; L[P_MPC + 1] = uy;
+        L[P_MPC + 2] = xp; L[P_MPC + 3] = xv; L[P_MPC + 4] = ux;
+        L[P_MPC + 5] = yp; L[P_MPC + 6] = yv; L[P_MPC + 7] = uy;
     }
-    *zcom_out = zcom;
+    if (lane < 3) {                                                // PDMomentumAcc (refs_pd_momentum); no angular momentum: h_ref[0:3] = kd (0 - 0)
+        const double posRef = (lane == 0) ? xp : (lane == 1) ? yp : zcom, velRef = (lane == 0) ? xv : (lane == 1) ? yv : 0.0;
+        const double accRef = (lane == 0) ? ux : (lane == 1) ? uy : 0.0;
+        const double cm = (lane == 0) ? cxp : (lane == 1) ? cyp : czp, cvl = (lane == 0) ? vxp : (lane == 1) ? vyp : vzp;
+        L[P_HREF + 3 + lane] = mass * (P.kp_mom * (posRef - cm) + P.kd_mom * (velRef - cvl) + accRef);
+        L[P_COMV + lane] = cvl;
+    }
+    if (ang) WSYNC();                                              // the angular rows of AG
+    if (lane < 3) {                                                // angular momentum AG_ang vhat and its PD term
+        double hs = 0.0;
+        if (ang) for (int c = 0; c < 30; c++) hs += L[P_AG + 30 * lane + c] * L[P_VHN + c];
+        L[P_ANGM + lane] = hs;
+        L[P_HREF + lane] = P.kd_mom * (0.0 - hs);
+    }
     return flags;
-}
-__device__ __forceinline__ void refs_pd_momentum(double *L, LmhCParams &P, double mass, double zcom)
-{
-    const int lane = LANE;
-    if (lane < 3) {                                                // PDMomentumAcc, controller.cpp:310-325
-        const double posRef = (lane == 0) ? L[P_MPC + 2] : (lane == 1) ? L[P_MPC + 5] : zcom;
-        const double velRef = (lane == 0) ? L[P_MPC + 3] : (lane == 1) ? L[P_MPC + 6] : 0.0;
-        const double accRef = (lane == 0) ? L[P_MPC + 4] : (lane == 1) ? L[P_MPC + 7] : 0.0;
-        L[P_HREF + 3 + lane] = mass * (P.kp_mom * (posRef - L[P_COM + lane]) + P.kd_mom * (velRef - L[P_COMV + lane]) + accRef);
-        L[P_HREF + lane] = P.kd_mom * (0.0 - L[P_ANGM + lane]);
-    }
 }
 // PDFeetAcc, orientation part (controller.cpp:344-353): kp_feet * (-R_des log(R_des' R_foot)) of both feet into P_FREF[6 ft + 0..2].  It needs
 // the soles' world transforms only (T7 at Ts, T14 at Ts + stride), not the Jacobian: in single support / flight the rollout's helper wave
@@ -1868,34 +1881,22 @@ __device__ __forceinline__ int phase_refs(double *L, LmhCParams &P, int inst, do
 {
     int flags = 0;
     const double mass = L[P_MODEL + 392];
-    double zcom = 0.0;
     const int k = __builtin_amdgcn_readfirstlane((int)L[P_RK]);   // the clock-only references of this evaluation (refs_prepare, before the first join)
     *k_out = k; *phase_out = __builtin_amdgcn_readfirstlane((int)L[P_RPH]);
     if (k < 0 || k + P.horizon >= P.n_samples) flags |= LMH_FLAG_ZMP_RANGE;    // on every wave (wave 0 reports)
     if constexpr (NW == 1) {
-        refs_ag(L, mass, ang);
+        flags |= refs_chain_a(L, P, inst, k, mass, ang);           // the same code on either schedule: the results agree bit for bit
         refs_agpqp<CGLIN>(L, mass, ang);
-        WSYNC();
         SUBSTAMP(12);
-        refs_momentum(L, mass, ang);
         refs_vfoot_pdjoints(L, P);
         WSYNC();
         SUBSTAMP(13);
-        flags |= refs_mpc(L, P, inst, k, &zcom);
-        WSYNC();
         SUBSTAMP(14);
-        refs_pd_momentum(L, P, mass, zcom);
         refs_pd_feet<false>(L, P, inst, t, k);
         WSYNC();
     } else if (wid == 1) {                                         // chain A
         WSTAMP(66);
-        refs_ag(L, mass, ang);
-        WSYNC();
-        refs_momentum(L, mass, ang);
-        WSYNC();
-        flags |= refs_mpc(L, P, inst, k, &zcom);
-        WSYNC();
-        refs_pd_momentum(L, P, mass, zcom);
+        flags |= refs_chain_a(L, P, inst, k, mass, ang);
         WSYNC();
     } else {                                                       // chain B
         WSTAMP(67);
@@ -2111,12 +2112,6 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double eps,
 // coefficients outside F come through the wrench: w = G_F z and W w by DPP row broadcasts on lanes 0..11 (z sits in lanes 0..7 of the same
 // 16-lane row), then lam_j = g_j . (W w - h) of the coefficient's foot: one LDS hand-over instead of four.
 // Returns like solve_free_set: z_j for lane j in F (0 otherwise), lam_j for lanes j < 32 outside F.
-#define LMH_DPP1(k) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf"
-template <int C>
-__device__ __forceinline__ void dpp_fmac_lane(double &acc, double src, double m)     // acc += lane_C(src) * m   (C < 16, own 16-lane row)
-{
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
-}
 // MODE 0: every free coefficient belongs to the right foot, 1: to the left foot (single support: the usual thin set), 2: mixed
 template <int C, int MODE>
 __device__ __forceinline__ void thin_cols(double *L, int nF, int (&idx)[8], const double (&uR)[6], const double (&uL)[6], double (&a)[8])
@@ -2799,7 +2794,9 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
     {   // lane = (row parity hi, column c); everything derived from the lane once, a pass is a load, one or two multiplications and the stores
         const int c = lane & 31, hi = lane >> 5, cs = (c < 30) ? c : 0;
         const double iDc = (c < 3) ? idp : (c < 6) ? ida : idj, dm = (c < 30) ? iDc : 0.0;          // 1 / D_c, 0 on the padding columns
-        if (wid == NW - 1) {                                       // rows 12..15 of U, U D^-1: the helper wave (wave 0 forms AGpqp and the weights meanwhile)
+        // NW = 2: all of these fills are wave 0's -- the helper is the later one at this join (it forms q meanwhile, and comes out of the longer
+        // reference chain), wave 0 used to wait ~0.7k cycles here (profiles/r04_barrier_share.txt)
+        if (wid == 0) {                                            // rows 12..15 of U, U D^-1
             const double um = (c < 30) ? 1.0 : 0.0;
             const double *ag = L + (P_AG + 90 + 30 * hi + cs);     // linear-momentum rows 3..5 of AG -> operand rows 12..14; row 15 is zero
             double *o = L + (Q_U + 34 * (12 + hi) + c);
@@ -2807,16 +2804,13 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
             o[0] = v0 * um; o[Q_UD - Q_U] = v0 * dm;
             o[68] = hi ? 0.0 : v1 * um; o[68 + (Q_UD - Q_U)] = hi ? 0.0 : v1 * dm;
         }
-        // rows 0..6 of bp'' = [-qref | D^-1 Mb'] (row 7 follows the join): wave w, row parity hi -> rows hi + 2 w and hi + 2 w + 4
-        const int n0 = hi + 2 * ((NW == 2) ? wid : 0);
-        {
+        // rows 0..6 of bp'' = [-qref | D^-1 Mb'] (row 7: q, below): row parity hi -> rows hi, hi + 4, then hi + 2 and 6
+        const int n0 = hi;
+        if (wid == 0) {
             const double *pa = L + ((n0 == 0) ? P_QREF + cs : P_MTOP + 30 * (n0 - 1) + cs);
             const double sa = (n0 == 0) ? ((c < 30) ? -1.0 : 0.0) : dm;
             L[Q_BPT + 34 * n0 + c] = pa[0] * sa;
-            const double *pb = L + (P_MTOP + 30 * (n0 + 3) + cs);  // rows 4, 5 (wave 0) | 6 (wave 1; row 7 is not a row of Mb: the store goes to the trash)
-            L[(n0 < 3) ? Q_BPT + 34 * (n0 + 4) + c : Q_TRASH + lane] = ((n0 < 3) ? pb : pa)[0] * dm;
-        }
-        if constexpr (NW == 1) {                                   // single-wave schedule: the other two row pairs as well
+            L[Q_BPT + 34 * (n0 + 4) + c] = L[P_MTOP + 30 * (n0 + 3) + cs] * dm;
             const int n1 = hi + 2;
             L[Q_BPT + 34 * n1 + c] = L[P_MTOP + 30 * (n1 - 1) + cs] * dm;
             if (hi == 0) L[Q_BPT + 34 * 6 + c] = L[P_MTOP + 30 * 5 + cs] * dm;
@@ -2840,7 +2834,6 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
         // cycles at the join below and then made wave 0 wait ~0.7k at the next one, behind this step (profiles/r04_barrier_share_mid2.txt).
         // It forms Om beta itself -- the same expressions wave 0 evaluates for Q_OB beside it -- in lane r of every 16-lane row and feeds it to
         // the column sums through DPP row broadcasts, so nothing has to come back through LDS: q_i = sum_r lane_r(Om beta) U[r][i].
-        WSYNC();                                                   // its own rows 12..14 of U
         const int l16 = lane & 15;
         const bool in = l16 < nU;
         const int rr = (l16 < 12) ? 6 + l16 : in ? 3 + (l16 - 12) : 3;          // row of [AG ; J] behind operand row l16
@@ -2854,10 +2847,12 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
         const double beta = (rr < 6) ? agp - L[P_HREF + rr] : bj;
         const double ob = in ? ((rr < 6) ? P.w_com_lin : P.w_foot) * beta : 0.0;
         const int ci = lane & 31;
-        const double *ucol = L + (Q_U + ci);
+        const double *ucol = L + (Q_U + ci), *agc = L + (P_AG + 90 + ((ci < 30) ? ci : 29));        // rows 12..14 of U = AG's linear rows (wave 0 is storing them beside this)
         double ur[nU];
 #pragma unroll
-        for (int r = 0; r < nU; r++) ur[r] = ucol[34 * r];
+        for (int r = 0; r < 12; r++) ur[r] = ucol[34 * r];
+#pragma unroll
+        for (int r = 12; r < nU; r++) ur[r] = agc[30 * (r - 12)];
         double q = 0.0;
         dpp_fmac_lane<0>(q, ob, ur[0]); dpp_fmac_lane<1>(q, ob, ur[1]); dpp_fmac_lane<2>(q, ob, ur[2]); dpp_fmac_lane<3>(q, ob, ur[3]);
         dpp_fmac_lane<4>(q, ob, ur[4]); dpp_fmac_lane<5>(q, ob, ur[5]); dpp_fmac_lane<6>(q, ob, ur[6]); dpp_fmac_lane<7>(q, ob, ur[7]);
