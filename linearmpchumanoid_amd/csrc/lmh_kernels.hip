@@ -635,10 +635,13 @@ __device__ __forceinline__ void dpp_fmac_self(double (&a)[N], double m)         
     }
 }
 #define LMH_DPP1(k) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf"
-template <int C>
+// NOP = false: `src` was not written by the instruction before (a DPP operand needs two wait states behind the VALU write of its register, and
+// the compiler does not look inside the asm): the later members of a chain on the same `src`
+template <int C, bool NOP = true>
 __device__ __forceinline__ void dpp_fmac_lane(double &acc, double src, double m)     // acc += lane_C(src) * m   (C < 16, own 16-lane row)
 {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
+    if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
 }
 // one pivot, then the next.  GUARD = true: `rowon` switches a whole 16-lane DPP row off (its pivots are replaced by 1) and a pivot that is
 // not above `dmin` is replaced by 1 and reported in `bad` (kinv_compute: two feet on two DPP rows, a rank-deficient K_f is an expected
@@ -1783,10 +1786,10 @@ __device__ __forceinline__ int refs_chain_a(double *L, LmhCParams &P, int inst, 
     o[c0] = ag0; o[c1] = ag1;                                       // (lanes 14, 15 repeat their first entry)
     const double part = ag0 * v0 + ag1 * v1, one = 1.0;
     double s0 = 0.0, s1 = 0.0;
-    dpp_fmac_lane<0>(s0, part, one); dpp_fmac_lane<1>(s1, part, one); dpp_fmac_lane<2>(s0, part, one); dpp_fmac_lane<3>(s1, part, one);
-    dpp_fmac_lane<4>(s0, part, one); dpp_fmac_lane<5>(s1, part, one); dpp_fmac_lane<6>(s0, part, one); dpp_fmac_lane<7>(s1, part, one);
-    dpp_fmac_lane<8>(s0, part, one); dpp_fmac_lane<9>(s1, part, one); dpp_fmac_lane<10>(s0, part, one); dpp_fmac_lane<11>(s1, part, one);
-    dpp_fmac_lane<12>(s0, part, one); dpp_fmac_lane<13>(s1, part, one); dpp_fmac_lane<14>(s0, part, one); dpp_fmac_lane<15>(s1, part, one);
+    dpp_fmac_lane<0>(s0, part, one); dpp_fmac_lane<1, false>(s1, part, one); dpp_fmac_lane<2, false>(s0, part, one); dpp_fmac_lane<3, false>(s1, part, one);
+    dpp_fmac_lane<4, false>(s0, part, one); dpp_fmac_lane<5, false>(s1, part, one); dpp_fmac_lane<6, false>(s0, part, one); dpp_fmac_lane<7, false>(s1, part, one);
+    dpp_fmac_lane<8, false>(s0, part, one); dpp_fmac_lane<9, false>(s1, part, one); dpp_fmac_lane<10, false>(s0, part, one); dpp_fmac_lane<11, false>(s1, part, one);
+    dpp_fmac_lane<12, false>(s0, part, one); dpp_fmac_lane<13, false>(s1, part, one); dpp_fmac_lane<14, false>(s0, part, one); dpp_fmac_lane<15, false>(s1, part, one);
     const double cv = (s0 + s1) / mass;                             // CoM velocity, component a, on every lane of row a
     const double vxp = readlane_f64(cv, 0), vyp = readlane_f64(cv, 16), vzp = readlane_f64(cv, 32);
     int flags = 0;
@@ -2194,9 +2197,9 @@ __device__ __forceinline__ int solve_free_set_thin(double *L, unsigned F_in, dou
         double wr[12];
 #pragma unroll
         for (int m2 = 0; m2 < 12; m2++) wr[m2] = Wk[m2];
-        dpp_fmac_lane<0>(y, wz, wr[0]); dpp_fmac_lane<1>(y, wz, wr[1]); dpp_fmac_lane<2>(y, wz, wr[2]); dpp_fmac_lane<3>(y, wz, wr[3]);
-        dpp_fmac_lane<4>(y, wz, wr[4]); dpp_fmac_lane<5>(y, wz, wr[5]); dpp_fmac_lane<6>(y, wz, wr[6]); dpp_fmac_lane<7>(y, wz, wr[7]);
-        dpp_fmac_lane<8>(y, wz, wr[8]); dpp_fmac_lane<9>(y, wz, wr[9]); dpp_fmac_lane<10>(y, wz, wr[10]); dpp_fmac_lane<11>(y, wz, wr[11]);
+        dpp_fmac_lane<0>(y, wz, wr[0]); dpp_fmac_lane<1, false>(y, wz, wr[1]); dpp_fmac_lane<2, false>(y, wz, wr[2]); dpp_fmac_lane<3, false>(y, wz, wr[3]);
+        dpp_fmac_lane<4, false>(y, wz, wr[4]); dpp_fmac_lane<5, false>(y, wz, wr[5]); dpp_fmac_lane<6, false>(y, wz, wr[6]); dpp_fmac_lane<7, false>(y, wz, wr[7]);
+        dpp_fmac_lane<8, false>(y, wz, wr[8]); dpp_fmac_lane<9, false>(y, wz, wr[9]); dpp_fmac_lane<10, false>(y, wz, wr[10]); dpp_fmac_lane<11, false>(y, wz, wr[11]);
     }
     WSYNC();                                                       // (the L rows parked by the solve are dead)
     L[(lane < 12) ? C_LS + lane : C_LS + 16 + (lane & 15)] = y;    // r = W w - h
@@ -2559,6 +2562,20 @@ __device__ __forceinline__ int cone_pushthrough_f32(double *L, LmhCParams &P, un
 // BPP_MAX rounds, a Lawson-Hanson active-set pass from the empty set finishes (monotone, finite).
 // One loop, one call site of the (large, fully unrolled) free-set solve.
 // P.bpp_max (lmh_config.bpp_rounds): 10 by default; < 0 skips block pivoting altogether (diagnostic: Lawson-Hanson from the empty set)
+// qv = G' h, the linear term of the cone problem (the Hessian G'WG + eps I itself is only formed if the general free-set solve is needed,
+// build_cone_matrix); G[k][j] is the generator of coefficient j (foot j / 16) in wrench rows 6 (j / 16) .. + 5.  Formed lazily: the all-free
+// solve -- the usual double-support case -- works on (W, h) and never reads it.
+__device__ __forceinline__ void qv_form(double *L)
+{
+    const int lane = LANE;
+    if (lane < 32) {
+        const int o = 6 * (lane / 16);
+        double sacc = 0.0;
+        for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
+        L[P_QV + lane] = sacc;
+    }
+    WSYNC();
+}
 template <bool F32 = false>
 __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced, unsigned *F_io, int *iters, int *w_done, double *dbgp = nullptr)
 {
@@ -2574,7 +2591,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
     const int bpp_max = P.bpp_max;
     bool lh = bpp_max < 0;                                         // false: block pivoting, true: Lawson-Hanson
     if (lh) F = 0u;
-    if (dbgp) build_cone_matrix(L, P);                             // the debug record dumps the 32 x 32 cone Hessian (the solves never form it)
+    if (dbgp) { build_cone_matrix(L, P); if constexpr (!F32) qv_form(L); }      // the debug record dumps the 32 x 32 cone Hessian (the solves never form it) and qv
     double cj = 0.0, lj = 0.0;
     if (!lh && forced == 0u && F == 0xFFFFFFFFu) {
         // every coefficient free (the usual balance case): then w = G c solves the 12 x 12 SPD system
@@ -2608,11 +2625,15 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
         WSTAMP(33);
         WSYNC();
         if (lane < 12) { L[P_U12 + lane] = b[0]; L[P_W12 + lane] = b[0]; }     // the wrench itself: G c = G G'(G G')^-1 u = u
-        WSYNC();
-        if (lane < 32) {
-            const double *gp = L + P_GPI + 6 * (lane & 15), *u = L + P_U12 + 6 * (lane >> 4);
+        {   // c = G'(G G')^-1 u: lanes 0..11 of every DPP row hold u, so the six terms of a foot come through row broadcasts (no way through LDS)
+            const double *gp = L + P_GPI + 6 * (lane & 15);
+            double g6[6], zr = 0.0, zl = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; k++) zj += gp[k] * u[k];
+            for (int k = 0; k < 6; k++) g6[k] = gp[k];
+            dpp_fmac_lane<0>(zr, b[0], g6[0]); dpp_fmac_lane<6, false>(zl, b[0], g6[0]); dpp_fmac_lane<1, false>(zr, b[0], g6[1]); dpp_fmac_lane<7, false>(zl, b[0], g6[1]);
+            dpp_fmac_lane<2, false>(zr, b[0], g6[2]); dpp_fmac_lane<8, false>(zl, b[0], g6[2]); dpp_fmac_lane<3, false>(zr, b[0], g6[3]); dpp_fmac_lane<9, false>(zl, b[0], g6[3]);
+            dpp_fmac_lane<4, false>(zr, b[0], g6[4]); dpp_fmac_lane<10, false>(zl, b[0], g6[4]); dpp_fmac_lane<5, false>(zr, b[0], g6[5]); dpp_fmac_lane<11, false>(zl, b[0], g6[5]);
+            zj = (lane < 32) ? ((lane & 16) ? zl : zr) : 0.0;
         }
         }
         WSTAMP(34);
@@ -2632,6 +2653,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
         F ^= bad;
     }
     // the dual sign tests of the iteration below scale with max |q| (the all-free path above has no dual side)
+    if constexpr (!F32) qv_form(L);
     double qmax = (lane < 32) ? fabs(L[P_QV + lane]) : 0.0;
     qmax = wave_max(qmax);
     WSTAMP(31);
@@ -2854,10 +2876,10 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
 #pragma unroll
         for (int r = 12; r < nU; r++) ur[r] = agc[30 * (r - 12)];
         double q = 0.0;
-        dpp_fmac_lane<0>(q, ob, ur[0]); dpp_fmac_lane<1>(q, ob, ur[1]); dpp_fmac_lane<2>(q, ob, ur[2]); dpp_fmac_lane<3>(q, ob, ur[3]);
-        dpp_fmac_lane<4>(q, ob, ur[4]); dpp_fmac_lane<5>(q, ob, ur[5]); dpp_fmac_lane<6>(q, ob, ur[6]); dpp_fmac_lane<7>(q, ob, ur[7]);
-        dpp_fmac_lane<8>(q, ob, ur[8]); dpp_fmac_lane<9>(q, ob, ur[9]); dpp_fmac_lane<10>(q, ob, ur[10]); dpp_fmac_lane<11>(q, ob, ur[11]);
-        dpp_fmac_lane<12>(q, ob, ur[12]); dpp_fmac_lane<13>(q, ob, ur[13]); dpp_fmac_lane<14>(q, ob, ur[14]);
+        dpp_fmac_lane<0>(q, ob, ur[0]); dpp_fmac_lane<1, false>(q, ob, ur[1]); dpp_fmac_lane<2, false>(q, ob, ur[2]); dpp_fmac_lane<3, false>(q, ob, ur[3]);
+        dpp_fmac_lane<4, false>(q, ob, ur[4]); dpp_fmac_lane<5, false>(q, ob, ur[5]); dpp_fmac_lane<6, false>(q, ob, ur[6]); dpp_fmac_lane<7, false>(q, ob, ur[7]);
+        dpp_fmac_lane<8, false>(q, ob, ur[8]); dpp_fmac_lane<9, false>(q, ob, ur[9]); dpp_fmac_lane<10, false>(q, ob, ur[10]); dpp_fmac_lane<11, false>(q, ob, ur[11]);
+        dpp_fmac_lane<12, false>(q, ob, ur[12]); dpp_fmac_lane<13, false>(q, ob, ur[13]); dpp_fmac_lane<14, false>(q, ob, ur[14]);
         const double iDi = (ci < 3) ? idp : (ci < 6) ? ida : idj;
         const double qr = -L[P_QREF + ((ci < 30) ? ci : 0)];
         L[Q_BPT + 34 * 7 + ci] = (ci < 30) ? qr + q * iDi : 0.0;   // (lanes 32..63 repeat lanes 0..31)
@@ -2982,35 +3004,29 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
             {
                 const int e = (lane < 36) ? lane : 0, i = e / 6, j = e % 6;
                 const double v = 0.5 * (L[Q_LS + 6 * i + j] + L[Q_LS + 6 * j + i]);
-                L[(lane < 36) ? P_SI + e : Q_TRASH + lane] = v;
+                L[(lane < 36) ? P_SI + e : Q_TRASH + lane] = v;    // (for the recovery; the tiles below symmetrise their own fragment)
             }
         }
-        WSYNC();
         WSTAMP(20);
-        {   // T1 = Jb Si (12 x 6), K = 6 in two k-steps: the lanes of k = 6, 7 (second step, tq >= 2) read zeros
-            const bool k2 = tq < 2;
-            const double *ja = (tr < 12) ? L + P_JC + 12 * tr + tq : zero, *sb = (tr < 6) ? L + P_SI + 6 * tq + tr : zero;   // B[k][n] = Si[k][n]
-            const double a0 = ja[0], b0 = sb[0], a1 = (k2 ? ja : zero)[k2 ? 4 : 0], b1 = (k2 ? sb : zero)[k2 ? 24 : 0];
-            v4d t1 = {0.0, 0.0, 0.0, 0.0};
-            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t1, 0, 0, 0);
-            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t1, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 3; g++) {                          // rows tq + 4 g < 12; columns 6, 7 come out as zeros (padding of the next tile)
-                const int m = tq + 4 * g;
-                L[(tr < 8) ? Q_T1 + 10 * m + tr : Q_TRASH + lane] = t1[g];
-            }
-        }
-        WSYNC();
-        WSTAMP(21);
-        {   // [W | h] = [w_force I + T1 Jb' | T1 d]
-            const bool k2 = tq < 2;
-            const double *ta = (tr < 12) ? L + Q_T1 + 10 * tr + tq : zero;
-            const double *jb = (tr < 12) ? L + P_JC + 12 * tr + tq : (tr == 12) ? L + P_D6 + tq : zero;
-            const double a0 = ta[0], a1 = ta[4];                   // T1 columns 6, 7 are zero
-            const double b0 = jb[0], b1 = (k2 ? jb : zero)[k2 ? 4 : 0];
+        {   // [W | h] = [w_force I + Jb Si Jb' | Jb Si d] as Jb (Si [Jb' | d]): the result fragment of the inner product, D[tq + 4 g][tr] in register g,
+            // IS the B fragment B[4 kk + tq][tr] of the outer one for kk = g, so the 6 x 13 intermediate never leaves the registers (the form
+            // (Jb Si) Jb' went through LDS twice: T1 out and back in the other fragment shape, behind a stored Si).
+            const bool k2 = tq < 2, r6 = tr < 6;
+            const int m6 = r6 ? tr : 0;
+            const double *ls = L + Q_LS;
+            const double s0 = 0.5 * (ls[6 * m6 + tq] + ls[6 * tq + m6]);                        // A[m = tr][k = tq] = Si[tr][tq], symmetrised
+            const double s1 = 0.5 * (ls[6 * m6 + (k2 ? 4 + tq : 0)] + ls[6 * (k2 ? 4 + tq : 0) + m6]);   // k = 4 + tq < 6
+            const double sa0 = r6 ? s0 : 0.0, sa1 = (r6 && k2) ? s1 : 0.0;
+            const double *jb = L + ((tr < 12) ? P_JC + 12 * tr + tq : (tr == 12) ? P_D6 + tq : P_D6);   // B[k][n] = Jb[n][k] | d[k] (n = 12) | 0
+            const double jv0 = jb[0], jv1 = jb[k2 ? 4 : 0];
+            const double b0 = (tr < 13) ? jv0 : 0.0, b1 = (tr < 13 && k2) ? jv1 : 0.0;
+            v4d xt = {0.0, 0.0, 0.0, 0.0};
+            xt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, b0, xt, 0, 0, 0);
+            xt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, b1, xt, 0, 0, 0);                    // xt[g] = (Si [Jb' | d])[tq + 4 g][tr]; rows 6, 7 are zero
+            const double a0 = (tr < 12) ? jv0 : 0.0, a1 = (tr < 12 && k2) ? jv1 : 0.0;          // A[m = tr][k] = Jb[tr][k]: the same loads
             v4d ww = {0.0, 0.0, 0.0, 0.0};
-            ww = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, ww, 0, 0, 0);
-            ww = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ww, 0, 0, 0);
+            ww = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xt[0], ww, 0, 0, 0);
+            ww = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xt[1], ww, 0, 0, 0);
             const double wf = P.w_force;
 #pragma unroll
             for (int g = 0; g < 3; g++) {
@@ -3020,14 +3036,7 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
         }
         WSTAMP(22);
         if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
-        WSYNC();
-        if (lane < 32) {                                           // qv = G' h
-            const int o = 6 * (lane / 16);
-            double sacc = 0.0;
-            for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
-            L[P_QV + lane] = sacc;
-        }
-        WSYNC();
+        WSYNC();                                                   // (qv = G' h: cone_qp, only if the all-free solve does not settle it)
         WSTAMP(23);
     }
     return flags;
@@ -3225,16 +3234,8 @@ __device__ __forceinline__ int qp_setup(double *L, LmhCParams &P, int wid, doubl
     if (dbgp && LANE == 0) dbgp[4011] = (double)clock64();
     // ---- qv = G' h (the cone Hessian G'WG + eps I itself is only formed if the general free-set solve is needed,
     //      build_cone_matrix); G[k][j] is the generator of coefficient j (foot j/16) in wrench rows 6 (j/16) .. +5
-    if (wid == 0) {
-        WSYNC();
-        if (lane < 32) {
-            const int o = 6 * (lane / 16);
-            double sacc = 0.0;
-            for (int k = 0; k < 6; k++) sacc += L[P_GCOL + 6 * (lane & 15) + k] * L[P_H12 + o + k];
-            L[P_QV + lane] = sacc;
-        }
-        WSYNC();
-    }
+    // (qv is formed by the cone solve when it needs it: cone_qp / qv_form)
+    if (wid == 0) WSYNC();
     WSTAMP(23);
     return flags;
 }
@@ -3347,22 +3348,28 @@ __device__ __forceinline__ int phase_qp(double *L, LmhCParams &P, int ph, int wi
         }
         WSYNC();
     }
-    if (lane < 6) {                                                // base columns of the feet Jacobian: P_JC[foot][row][0..5]
-        double s = 0.0;
+    {   // the three products in registers: lane l16 of every DPP row holds w[l16], r and lam come out in lanes 0..5 of every row, and each
+        // sum takes its terms through row broadcasts -- one read of the wrench instead of three LDS round trips on the path both waves wait for
+        const int l16 = lane & 15, i6 = (l16 < 6) ? l16 : 0, j = lane & 31, js = (j < 30) ? j : 0;
+        const double wv = L[P_W12 + ((l16 < 12) ? l16 : 0)];
+        const double *jc = L + P_JC + i6, *si = L + P_SI + 6 * i6, *yt = L + P_YT + js;      // base columns of the feet Jacobian: P_JC[foot][row][0..5]
+        double jm[12], sm[6], ym[6];
 #pragma unroll
-        for (int row = 0; row < 12; row++) s += L[P_JC + 72 * (row / 6) + 12 * (row % 6) + lane] * L[P_W12 + row];
-        L[P_LAM6 + lane] = s - L[P_D6 + lane];                     // r = Jb' w - d (temporarily)
-    }
-    WSYNC();
-    double lam = 0.0;
-    if (lane < 6) { for (int k = 0; k < 6; k++) lam += L[P_SI + 6 * lane + k] * L[P_LAM6 + k]; lam = -lam; }
-    WSYNC();
-    if (lane < 6) L[P_LAM6 + lane] = lam;
-    WSYNC();
-    if (lane < 30) {
-        double s = L[P_YT + lane];
-        for (int k = 0; k < 6; k++) s += L[P_YT + 30 * (1 + k) + lane] * L[P_LAM6 + k];
-        L[P_A + lane] = -s;
+        for (int row = 0; row < 12; row++) jm[row] = jc[72 * (row / 6) + 12 * (row % 6)];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { sm[k] = si[k]; ym[k] = yt[30 * (1 + k)]; }
+        double r0 = -L[P_D6 + i6], r1 = 0.0, s = yt[0];
+        dpp_fmac_lane<0>(r0, wv, jm[0]); dpp_fmac_lane<1, false>(r1, wv, jm[1]); dpp_fmac_lane<2, false>(r0, wv, jm[2]); dpp_fmac_lane<3, false>(r1, wv, jm[3]);
+        dpp_fmac_lane<4, false>(r0, wv, jm[4]); dpp_fmac_lane<5, false>(r1, wv, jm[5]); dpp_fmac_lane<6, false>(r0, wv, jm[6]); dpp_fmac_lane<7, false>(r1, wv, jm[7]);
+        dpp_fmac_lane<8, false>(r0, wv, jm[8]); dpp_fmac_lane<9, false>(r1, wv, jm[9]); dpp_fmac_lane<10, false>(r0, wv, jm[10]); dpp_fmac_lane<11, false>(r1, wv, jm[11]);
+        const double r = r0 + r1;                                  // r = Jb' w - d
+        double nl = 0.0;
+        dpp_fmac_lane<0>(nl, r, sm[0]); dpp_fmac_lane<1, false>(nl, r, sm[1]); dpp_fmac_lane<2, false>(nl, r, sm[2]);
+        dpp_fmac_lane<3, false>(nl, r, sm[3]); dpp_fmac_lane<4, false>(nl, r, sm[4]); dpp_fmac_lane<5, false>(nl, r, sm[5]);
+        const double lam = -nl;                                    // lam = -Si r  (nothing else reads it)
+        dpp_fmac_lane<0>(s, lam, ym[0]); dpp_fmac_lane<1, false>(s, lam, ym[1]); dpp_fmac_lane<2, false>(s, lam, ym[2]);
+        dpp_fmac_lane<3, false>(s, lam, ym[3]); dpp_fmac_lane<4, false>(s, lam, ym[4]); dpp_fmac_lane<5, false>(s, lam, ym[5]);
+        if (lane < 30) L[P_A + lane] = -s;                         // a = -(Y_g + Y_M lam)
     }
     WSYNC();
     WSTAMP(26);
