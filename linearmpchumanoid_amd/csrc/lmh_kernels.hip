@@ -62,7 +62,7 @@ __device__ __forceinline__ void bsync()
 {
     if constexpr (NW == 1) WSYNC();
     else {
-#ifdef LMH_SUBSTAMPS
+#if defined(LMH_SUBSTAMPS) && !defined(LMH_DIAG_TL)               // (the production-timeline build keeps the plain barrier: its stamps bracket the joins)
         const long long t0 = clock64();
         __syncthreads();
         if ((threadIdx.x & 63u) == 0) {
@@ -242,15 +242,32 @@ __device__ __forceinline__ int lane_opaque()
 // shipped kernels execute no stamp.  Only the debug kernel points g_dbg at its dump buffer.
 #ifdef LMH_SUBSTAMPS
 __shared__ double *g_dbg;
+__shared__ unsigned g_rt[6];          // cone-solve route counts of the robot's launch: all-free accepted | push-through | thin | general rounds | evaluations | all-free tried
+#define RT_COUNT(i) do { if (LANE == 0) g_rt[i] += 1u; } while (0)
+#ifdef LMH_DIAG_TL
+__shared__ double *g_tl[2];
+#endif
 #define SUBSTAMP(i) do { if (g_dbg && LANE == 0) g_dbg[3900 + (i)] = (double)clock64(); } while (0)
+#ifdef LMH_DIAG_TL
+#define SET_GDBG(p) do { if (LANE == 0) { g_dbg = (p); g_tl[threadIdx.x >> 6] = nullptr; } } while (0)      // (every kernel starts with it)
+#else
 #define SET_GDBG(p) do { if (LANE == 0) g_dbg = (p); } while (0)
+#endif
 // per-wave timeline (two-wave debug kernel): wave w stamps slot 3700 + 100 w + i (scripts/gpu_wave_timeline.py)
+#ifdef LMH_DIAG_TL
+// ... of the PRODUCTION rollout kernel (scripts/diag.py ptimeline): the evaluation of Runge-Kutta stage LMH_DIAG_TL in the launch's last tick
+// stamps into the log buffer, 256 doubles per robot (wave w: [100 w + i]); each wave switches its own pointer on and off
+#define WSTAMP(i) do { double *p_ = g_tl[threadIdx.x >> 6]; if (p_ && LANE == 0) p_[100 * (int)(threadIdx.x >> 6) + (i)] = (double)clock64(); } while (0)
+#else
 #define WSTAMP(i) do { if (g_dbg && LANE == 0) g_dbg[3700 + 100 * (int)(threadIdx.x >> 6) + (i)] = (double)clock64(); } while (0)
+#endif
 #elif defined(LMH_PMARK)                 // static instruction census: the stamps become comments in the ISA listing (scripts/isa_census.py)
 #define SUBSTAMP(i) do { } while (0)
 #define SET_GDBG(p) do { } while (0)
 #define WSTAMP(i) asm volatile("; PMARK " #i)
+#define RT_COUNT(i) do { } while (0)
 #else
+#define RT_COUNT(i) do { } while (0)
 #define SUBSTAMP(i) do { } while (0)
 #define SET_GDBG(p) do { } while (0)
 #define WSTAMP(i) do { } while (0)
@@ -2116,14 +2133,20 @@ __device__ __forceinline__ int solve_free_set(double *L, unsigned F, double eps,
 // 16-lane row), then lam_j = g_j . (W w - h) of the coefficient's foot: one LDS hand-over instead of four.
 // Returns like solve_free_set: z_j for lane j in F (0 otherwise), lam_j for lanes j < 32 outside F.
 // MODE 0: every free coefficient belongs to the right foot, 1: to the left foot (single support: the usual thin set), 2: mixed
-template <int C, int MODE>
-__device__ __forceinline__ void thin_cols(double *L, int nF, int (&idx)[8], const double (&uR)[6], const double (&uL)[6], double (&a)[8])
+// NT = 8 | 16 rows.  NT = 16 is the double-support set right after a touch-down: both feet press on one edge of their polygons (two vertices,
+// 4 + 4 rays each: F = 0f0f0f0f for ~130 of the 200 ticks of every double-support phase of the walking workload, scripts/route_probe.py); each
+// foot's K_f = G_F G_F' then has rank 5, the push-through route does not apply, and the |F| x |F| solve through the LDS image took 16.8k
+// cycles of such an evaluation (profiles/r04_prod_timeline.txt).
+// The set bits of F are walked with a scalar mask (no index array held in scalar registers across the solve).
+template <int NT, int C, int MODE>
+__device__ __forceinline__ void thin_cols(double *L, int nF, unsigned m, const double (&uR)[6], const double (&uL)[6], double (&a)[NT])
 {
-    if constexpr (C < 8) {
+    if constexpr (C < NT) {
         if (C < nF) {                                              // wave-uniform
-            const double *g = L + P_GCOL + 6 * (idx[C] & 15);
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctz(m));
+            const double *g = L + P_GCOL + 6 * (j & 15);
             double sacc = 0.0;
-            if (MODE == 1 || (MODE == 2 && (idx[C] >> 4))) {
+            if (MODE == 1 || (MODE == 2 && (j >> 4))) {
 #pragma unroll
                 for (int b = 0; b < 6; b++) sacc += uL[b] * g[b];
             } else {
@@ -2132,34 +2155,36 @@ __device__ __forceinline__ void thin_cols(double *L, int nF, int (&idx)[8], cons
             }
             a[C] = sacc;
         } else a[C] = 0.0;
-        thin_cols<C + 1, MODE>(L, nF, idx, uR, uL, a);
+        thin_cols<NT, C + 1, MODE>(L, nF, m & (m - 1u), uR, uL, a);
     }
 }
-template <int C>
-__device__ __forceinline__ void thin_wrench(double *L, int nF, int (&idx)[8], double z, int kk, bool leftlane, double &wz)
+template <int NT, int C>
+__device__ __forceinline__ void thin_wrench(double *L, int nF, unsigned m, double z, int kk, bool leftlane, double &wz)
 {
-    if constexpr (C < 8) {
+    if constexpr (C < NT) {
         if (C < nF) {                                              // wave-uniform
-            const bool match = ((idx[C] >> 4) != 0) == leftlane;   // the coefficient pushes on this lane's foot
-            const double gv = L[P_GCOL + 6 * (idx[C] & 15) + kk];  // (no zero slot of the set-up scratch survives the cone phase: select on the value)
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctz(m));
+            const bool match = ((j >> 4) != 0) == leftlane;        // the coefficient pushes on this lane's foot
+            const double gv = L[P_GCOL + 6 * (j & 15) + kk];       // (no zero slot of the set-up scratch survives the cone phase: select on the value)
             dpp_fmac_lane<C>(wz, z, match ? gv : 0.0);
         }
-        thin_wrench<C + 1>(L, nF, idx, z, kk, leftlane, wz);
+        thin_wrench<NT, C + 1>(L, nF, m & (m - 1u), z, kk, leftlane, wz);
     }
 }
+template <int NT>
 __device__ __forceinline__ int solve_free_set_thin(double *L, unsigned F_in, double eps, double *z_out, double *lam_out)
 {
     const int lane = LANE;
     const unsigned F = (unsigned)__builtin_amdgcn_readfirstlane((int)F_in);       // wave-uniform by construction (ballots); make it a scalar
     const int nF = __popc(F);
-    int idx[8], ia = 0;
+    int ia = 0;
     {
         unsigned m = F;
 #pragma unroll
-        for (int c = 0; c < 8; c++) {                              // scalar bit scan; lane c learns its coefficient through one v_writelane
-            idx[c] = __builtin_amdgcn_readfirstlane(m ? __builtin_ctz(m) : 0);        // (a scalar register whatever the compiler thinks of F)
+        for (int c = 0; c < NT; c++) {                             // scalar bit scan; lane c learns its coefficient through one v_writelane
+            const int jc = __builtin_amdgcn_readfirstlane(m ? __builtin_ctz(m) : 0);  // (a scalar register whatever the compiler thinks of F)
             m &= m - 1u;
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(ia) : "s"(idx[c]), "n"(c));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(ia) : "s"(jc), "n"(c));
         }
     }
     double uR[6] = {0, 0, 0, 0, 0, 0}, uL[6] = {0, 0, 0, 0, 0, 0};
@@ -2177,19 +2202,22 @@ __device__ __forceinline__ int solve_free_set_thin(double *L, unsigned F_in, dou
             for (int b = 0; b < 6; b++) { double sl = 0.0; for (int a = 0; a < 6; a++) sl += g[a] * Wr[12 * a + 6 + b]; uL[b] = sl; }
         }
     }
-    double a[8], b[1];
-    if ((F >> 16) == 0u) thin_cols<0, 0>(L, nF, idx, uR, uL, a);     // wave-uniform three-way: no per-column choice between u_R and u_L in the usual cases
-    else if ((F & 0xFFFFu) == 0u) thin_cols<0, 1>(L, nF, idx, uR, uL, a);
-    else thin_cols<0, 2>(L, nF, idx, uR, uL, a);
+    double a[NT], b[1];
+    if constexpr (NT == 16) thin_cols<NT, 0, 2>(L, nF, F, uR, uL, a);       // (9..16 free coefficients with a singular K_f: both feet)
+    else {
+        if ((F >> 16) == 0u) thin_cols<NT, 0, 0>(L, nF, F, uR, uL, a);       // wave-uniform three-way: no per-column choice between u_R and u_L in the usual cases
+        else if ((F & 0xFFFFu) == 0u) thin_cols<NT, 0, 1>(L, nF, F, uR, uL, a);
+        else thin_cols<NT, 0, 2>(L, nF, F, uR, uL, a);
+    }
     b[0] = L[P_QV + ia];
-    const int bad = ldl_solve_regs<8, 1>(a, b, (1u << nF) - 1u, L + C_LS, eps);     // + eps I: added where the pivots are read
+    const int bad = ldl_solve_regs<NT, 1>(a, b, (nF >= 32) ? 0xFFFFFFFFu : ((1u << nF) - 1u), L + C_LS, eps);     // + eps I: added where the pivots are read
     const double z = (lane < nF) ? b[0] : 0.0;                     // z_r in lane r; lanes 8..15 of the row must read as zeros below
     // w = G_F z (lanes 0..11: component kk of foot lane / 6), y = W w, r = y - h
     const int l12 = (lane < 12) ? lane : 0;
     const bool leftlane = l12 >= 6;
     const int kk = l12 - (leftlane ? 6 : 0);
     double wz = 0.0;
-    thin_wrench<0>(L, nF, idx, z, kk, leftlane, wz);
+    thin_wrench<NT, 0>(L, nF, F, z, kk, leftlane, wz);
     L[(lane < 12) ? P_W12 + lane : (int)P_DUMP] = wz;              // the wrench G c itself: if this set is accepted the recovery starts from it (cone_qp: w_done)
     double y = -L[P_H12 + l12];
     {
@@ -2204,7 +2232,7 @@ __device__ __forceinline__ int solve_free_set_thin(double *L, unsigned F_in, dou
     WSYNC();                                                       // (the L rows parked by the solve are dead)
     L[(lane < 12) ? C_LS + lane : C_LS + 16 + (lane & 15)] = y;    // r = W w - h
     const int pos = __popc(F & ((1u << (lane & 31)) - 1u));
-    const double zr = __shfl(z, pos & 7, 64);                      // coefficient j <- row pos(j)
+    const double zr = __shfl(z, pos & (NT - 1), 64);               // coefficient j <- row pos(j)
     const bool inF = (lane < 32) && ((F >> lane) & 1u);
     const double zj = inF ? zr : 0.0;
     WSYNC();
@@ -2230,13 +2258,32 @@ __device__ __forceinline__ int solve_free_set_thin(double *L, unsigned F_in, dou
 // per DPP row) and a 12 x 12 solve replace the |F| x |F| factorisation.  A foot without any free coefficient
 // carries no force (its rows are dropped).  Returns 0 (wave-uniform) when some K_f is numerically singular: the
 // caller then takes the general P_FF solve.
+// EDGE CONTACT.  A foot whose free coefficients all sit on two vertices of one side of the sole (coefficient j = 4 vertex + ray; vertices 0, 2
+// have p_y = +0.025, 1, 3 p_y = -0.025, 0, 1 p_x = 0.1, 2, 3 p_x = -0.05, Robot.cpp:38-42) pushes along a line: its wrench obeys tau_x = p_y f_z
+// (side edges) or tau_y = -p_x f_z (front / back edge), K_f has rank 5 and the identity above does not apply as it stands.  It does in the
+// five free wrench coordinates: with w = E w~ (E = I but for the row of the bound torque, which reads kappa times f_z; w~ has a 0 there),
+// K~ = K_f without that row and column, the minimiser is c_F = G_F' y~ with y~ = K~^-1 w~ and (E'WE + eps K~^-1) w~ = E'h -- the same 12 x 12
+// solve with one row / column folded into the f_z one and pinned (unit pivot, zero right-hand side).  The multipliers of the foot's other
+// coefficients are g_j'(W w - h) with the true residual (its bound component is not -eps y~).  This is the double-support set right after a
+// touch-down of the walking workload: F = 0f0f0f0f for ~130 of the 200 ticks of every double-support phase (scripts/route_probe.py), which
+// the |F| x |F| solve answered in 16.8k cycles of such an evaluation (profiles/r04_prod_timeline.txt).
+// d: 0 = tau_x bound, 1 = tau_y bound, -1 = none (wave-uniform, from the foot's 16-bit free mask)
+__device__ __forceinline__ int edge_bound_row(unsigned Ff)
+{
+    if (Ff == 0u) return -1;
+    if ((Ff & ~0x0F0Fu) == 0u || (Ff & ~0xF0F0u) == 0u) return 0;
+    if ((Ff & ~0x00FFu) == 0u || (Ff & ~0xFF00u) == 0u) return 1;
+    return -1;
+}
 // K_f^-1 of both feet for the free set F into Kdst (2 x 36); `scr` = 160 doubles of scratch.  Returns non-zero
-// (wave-uniform) when a foot with free coefficients has a singular K_f.
+// (wave-uniform) when a foot with free coefficients has a singular K_f (edge contact: a singular K~; the row / column of the bound torque
+// of the stored inverse are zero).
 __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst, double *scr)
 {
     const int lane = LANE, l16 = lane & 15, row = lane >> 4;
     const unsigned FR = F & 0xFFFFu, FL = F >> 16;
     const bool useR = FR != 0u, useL = FL != 0u;
+    const int dR = edge_bound_row(FR), dL = edge_bound_row(FL);
     double *K = scr, *Ki = Kdst;
     WSYNC();
     {   // K_f = G diag(free_f) G' for both feet as ONE 16 x 16 x 16 matrix-core product: row block f of A carries foot f's
@@ -2260,15 +2307,20 @@ __device__ __forceinline__ int kinv_compute(double *L, unsigned F, double *Kdst,
         const bool on = rowon && l16 < 6;
         const int rb = (row < 2) ? 36 * row : 0, lr = (l16 < 6) ? l16 : 0;
         double a[6], bb[6], myinv = 0.0;
+        const int dd = (row == 0) ? dR : dL;                       // bound torque row of this DPP row's foot (-1: none)
 #pragma unroll
-        for (int c = 0; c < 6; c++) { a[c] = K[rb + 6 * lr + c]; bb[c] = (l16 == c) ? 1.0 : 0.0; }      // full rows (Gauss-Jordan), both feet at once
+        for (int c = 0; c < 6; c++) {                              // full rows (Gauss-Jordan), both feet at once; the bound row / column pinned
+            const double kv = K[rb + 6 * lr + c];
+            a[c] = (l16 == dd || c == dd) ? ((l16 == c) ? 1.0 : 0.0) : kv;
+            bb[c] = (l16 == c) ? 1.0 : 0.0;
+        }
         // K_f entries are O(1e-3 .. 10); a rank-deficient block pivots at ~1e-17
         gj16_step<0>(a, bb, 0x3Fu, l16, rowon, 1e-12, bad, myinv);
 #pragma unroll
         for (int c = 0; c < 6; c++) bb[c] *= myinv;
         if (row < 2 && l16 < 6) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) Ki[36 * row + 6 * l16 + c] = on ? bb[c] : 0.0;       // K_f^-1 (symmetric); 0 for a foot without force
+            for (int c = 0; c < 6; c++) Ki[36 * row + 6 * l16 + c] = (on && l16 != dd && c != dd) ? bb[c] : 0.0;       // K_f^-1 (symmetric); 0 for a foot without force
         }
     }
     WSYNC();
@@ -2285,44 +2337,66 @@ __device__ __forceinline__ int cone_pushthrough(double *L, LmhCParams &P, unsign
     if (have_ki == 2) return 0;
     if (have_ki == 0 && kinv_compute(L, F, L + C_LS + 72, L + C_LS + 240)) return 0;     // wave-uniform: some K_f is singular
     WSYNC();
-    {   // (W + eps K^-1) w = h on the rows of the feet that carry force
+    const int dR = edge_bound_row(FR), dL = edge_bound_row(FL);    // edge contact: the bound torque row of the foot (-1: none); wave-uniform
+    const double kR = L[P_GCOL + 6 * (FR ? __builtin_ctz(FR) : 0) + ((dR > 0) ? 1 : 0)], kL = L[P_GCOL + 6 * (FL ? __builtin_ctz(FL) : 0) + ((dL > 0) ? 1 : 0)];
+    const double kapR = (dR >= 0) ? kR : 0.0, kapL = (dL >= 0) ? kL : 0.0;      // tau_bound = kappa f_z: p_y | -p_x of the edge, the generator's own entry
+    {   // (E'WE + eps K~^-1) w~ = E'h on the rows of the feet that carry force (E = I, K~ = K without edge contact)
         double a[12], b[1];
         const int l16 = lane & 15, lr = (l16 < 12) ? l16 : 0, fi = (lr >= 6) ? 1 : 0, ri = lr - 6 * fi;          // (a copy of the system per DPP row)
-        const bool rowuse = (lane < 12) && ((fi == 0) ? useR : useL);
+        const bool rowuse = (l16 < 12) && ((fi == 0) ? useR : useL);
+        const int dd = fi ? dL : dR;
+        const bool rowpin = ri == dd, isz = (ri == 5) && (dd >= 0);
+        const double kz = isz ? (fi ? kapL : kapR) : 0.0;          // the f_z row takes kappa times the bound row
         const double eps = P.eps_coeff;
+        const double *W1 = L + P_W + 12 * lr, *W2 = L + P_W + 12 * (6 * fi + ((dd > 0) ? dd : 0)), *Kr = Ki + 36 * fi + 6 * ri;
+        double base[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) base[c] = W1[c] + kz * W2[c];
+        base[5] += kapR * ((dR > 0) ? base[1] : base[0]);           // ... and the f_z column kappa times the bound column (kappa = 0: no edge)
+        base[11] += kapL * ((dL > 0) ? base[7] : base[6]);
 #pragma unroll
         for (int c = 0; c < 12; c++) {                             // full rows, unconditional loads: rows / columns of a foot without force are
-            const double g = Ki[36 * fi + 6 * ri + c % 6];         // never pivots (live mask), so their entries are don't-cares
-            a[c] = L[P_W + 12 * lr + c] + ((c / 6 == fi) ? eps * g : 0.0);
+            const double g = Kr[c % 6];                            // never pivots (live mask), so their entries are don't-cares
+            const bool colpin = (c % 6) == ((c < 6) ? dR : dL);
+            const double v = base[c] + ((c / 6 == fi) ? eps * g : 0.0);
+            a[c] = (rowpin || colpin) ? ((lr == c) ? 1.0 : 0.0) : v;
         }
-        b[0] = L[P_H12 + lr];
+        const double hv = L[P_H12 + lr] + kz * L[P_H12 + 6 * fi + ((dd > 0) ? dd : 0)];
+        b[0] = rowpin ? 0.0 : hv;
         const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
         if (gj_solve_regs<12, 1>(a, b, live)) *flags |= LMH_FLAG_NOT_SPD;
+        // w = E w~: the bound torque is kappa f_z (lanes 5 / 11 of the lane's own 16-lane row hold f_z)
+        const double fzR = bcast16<5>(b[0]), fzL = bcast16<11>(b[0]);
+        const double wv = rowpin ? (fi ? kapL * fzL : kapR * fzR) : b[0];
         WSYNC();
-        if (lane < 12) Yv[lane] = rowuse ? b[0] : 0.0;             // w
+        if (lane < 12) { const double wo = rowuse ? wv : 0.0; Yv[lane] = wo; L[P_W12 + lane] = wo; }      // w: the wrench G c itself (cone_qp: w_done if the round is accepted)
     }
     WSYNC();
-    if (lane < 12) {                                               // y = K^-1 w, foot by foot
+    if (lane < 12) {                                               // y = K~^-1 w (free coefficients), -(W w - h) / eps (the others), foot by foot
         const int fi = lane / 6, ri = lane % 6;
-        const bool used = (fi == 0) ? useR : useL;
-        double yv = 0.0;
+        const bool used = (fi == 0) ? useR : useL, edge = (fi ? dL : dR) >= 0;
+        double yv = 0.0, yn = 0.0;
         if (used) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) yv += Ki[36 * fi + 6 * ri + k] * Yv[6 * fi + k];
-        } else {
-            // a foot with no free coefficient: its multipliers are g_j'(W w - h) with the foot's rows of the residual;
+            for (int k = 0; k < 6; k++) yv += Ki[36 * fi + 6 * ri + k] * Yv[6 * fi + k];     // (the bound column of the inverse is zero)
+            yn = yv;                                               // K regular: g_j'(W w - h) = -eps g_j'y for every coefficient of the foot
+        }
+        if (!used || edge) {
+            // a foot with no free coefficient, or on an edge: the multipliers are g_j'(W w - h) with the foot's rows of the residual;
             // stored as -(W w - h)/eps so that the caller's -eps s_j reproduces them
             double rv = -L[P_H12 + lane];
 #pragma unroll
             for (int k = 0; k < 12; k++) rv += L[P_W + 12 * lane + k] * Yv[k];
-            yv = -rv / P.eps_coeff;
+            yn = -rv / P.eps_coeff;
+            if (!used) yv = yn;
         }
-        Yv[12 + lane] = yv;
+        Yv[12 + lane] = yv; Yv[24 + lane] = yn;
     }
     WSYNC();
     double sj = 0.0;
     if (lane < 32) {
-        const double *g = L + P_GCOL + 6 * (lane & 15), *y = Yv + 12 + 6 * (lane >> 4);
+        const bool fr = (F >> lane) & 1u;
+        const double *g = L + P_GCOL + 6 * (lane & 15), *y = Yv + (fr ? 12 : 24) + 6 * (lane >> 4);
 #pragma unroll
         for (int k = 0; k < 6; k++) sj += g[k] * y[k];
     }
@@ -2585,6 +2659,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
     forced = (unsigned)__builtin_amdgcn_readfirstlane((int)forced);
     unsigned F = (unsigned)__builtin_amdgcn_readfirstlane((int)(*F_io & ~forced));    // scalar from here on (ballots keep it so)
     WSTAMP(30);
+    RT_COUNT(4);
     *w_done = 0;
     const bool mine = (lane < 32) && !((forced >> lane) & 1u);
     int ninf = 33, budget = 3;
@@ -2598,6 +2673,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
         // (W + eps (G G')^-1) w = h and c = G'(G G')^-1 w  (push-through identity; G G' is constant,
         // block diagonal and well conditioned) -- 12 pivots instead of 32.
         it++;
+        RT_COUNT(5);
         double zj = 0.0;
         if constexpr (F32) {
             WSYNC();
@@ -2642,6 +2718,7 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
         WSTAMP(35);
         cj = zj;
         if (bad == 0u) {
+            RT_COUNT(0);
             WSYNC();
             if (lane < 32) L[P_CC + lane] = cj;
             WSYNC();
@@ -2665,13 +2742,15 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
         double zj;
         if (dbgp && lane == 0 && it <= 12) dbgp[4020 + 2 * it] = (double)clock64();
         double sj;
-        bool w_thin = false;                                       // this round's solve left the wrench G z in P_W12
+        bool w_thin = false;                                       // this round's solve left the wrench G z in P_W12 (thin sets; push-through: w itself)
         const int have_ki = F32 ? 0 : __builtin_amdgcn_readfirstlane((F == (unsigned)L[P_KF + 1]) ? (int)L[P_KF + 2] : 0);   // prepared by the helper wave for the warm-start set
         double tolm = toll;                                        // dual sign test of this round
         bool pt;
         if constexpr (F32) pt = !lh && cone_pushthrough_f32(L, P, F, &sj, &flags);
         else pt = !lh && cone_pushthrough(L, P, F, have_ki, &sj, &flags);
         if (pt) {                                                  // 12 x 12 route: coefficients and multipliers from one vector
+            RT_COUNT(1);
+            w_thin = !F32;
             const bool fr = (lane < 32) && ((F >> lane) & 1u);
             zj = fr ? sj : 0.0;
             lj = (lane < 32 && !fr) ? -P.eps_coeff * sj : 0.0;
@@ -2690,11 +2769,21 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
             if (__builtin_amdgcn_readfirstlane(__popc(F)) <= 8) {  // thin set (wave-uniform): everything in registers
 #endif
                 WSTAMP(80);
-                if (solve_free_set_thin(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+                RT_COUNT(2);
+                if (solve_free_set_thin<8>(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
                 w_thin = true;
                 WSTAMP(81);
+#ifndef LMH_NO_THIN16
+            } else if (__builtin_amdgcn_readfirstlane(__popc(F)) <= 16) {      // up to 16 rows: the same solve, one DPP row full
+                WSTAMP(84);
+                RT_COUNT(2);
+                if (solve_free_set_thin<16>(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
+                w_thin = true;
+                WSTAMP(85);
+#endif
             } else {
                 WSTAMP(82);
+                RT_COUNT(3);
                 build_cone_rows(L, F, P.eps_coeff);                // P_FF only (the multipliers go through the wrench G z)
                 if (solve_free_set(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
                 WSTAMP(83);
@@ -3931,7 +4020,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
     if constexpr (std::is_same_v<R, double>) ibp = ib_pack();      // the matrix-core CRBA's gather table, two registers for the whole chunk
     const double dt = P.dt;
 #ifdef LMH_SUBSTAMPS
-    if (lane == 0) { L[D_BWAIT + wid] = 0.0; for (int j_ = 0; j_ < 8; j_++) L[D_JWAIT + 8 * wid + j_] = 0.0; }
+    if (lane == 0) { L[D_BWAIT + wid] = 0.0; for (int j_ = 0; j_ < 8; j_++) L[D_JWAIT + 8 * wid + j_] = 0.0; if (wid == 0) for (int j_ = 0; j_ < 6; j_++) g_rt[j_] = 0u; }
     __syncthreads();
     const long long t_launch = clock64(), t_real = wall_clock64();
 #endif
@@ -3953,6 +4042,10 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             }
             LmhCParams *Pe = Pc;
             asm volatile("" : "+s"(Pe));                           // opaque: the loads below belong to this evaluation
+#ifdef LMH_DIAG_TL
+            if (lane == 0) g_tl[wid] = (log && tick0 + tick == n_ticks - 1 && stage == LMH_DIAG_TL) ? log + (size_t)256 * inst : nullptr;
+            WSYNC();
+#endif
 #ifdef LMH_SUBSTAMPS
 #ifdef LMH_DIAG_STAGE                                              // the per-join split of ONE Runge-Kutta stage's evaluations (the others land in slot 7)
             if (lane == 0) L[D_JIDX + wid] = (stage == LMH_DIAG_STAGE) ? 0.0 : 100.0;
@@ -3992,8 +4085,17 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
                 if (lane >= 30 && lane < 60) L[P_VP + lane - 30] = xprev;
             }
             WSTAMP(72);
+#ifdef LMH_DIAG_TL
+            WSYNC();
+            if (lane == 0) g_tl[wid] = nullptr;
+            WSYNC();
+#endif
         }
+#ifdef LMH_DIAG_TL
+        if (false) {
+#else
         if (log) {                                                  // each wave logs what it produced: wave 1 the torques, wave 0 the wrench
+#endif
             double *lg = log + ((size_t)(tick0 + tick) * P.n_instances + inst) * 36;
             if (wid != 0) { if (lane < 24) lg[lane] = L[P_TAU + lane]; }
             else if (lane >= 24 && lane < 36) lg[lane] = L[P_W12 + lane - 24];
@@ -4021,6 +4123,7 @@ lmh_rollout_kernel(const LmhDevParams *__restrict__ Pg, int *__restrict__ ticket
             o_[62] = (first_ ? 0.0 : o_[62]) + (double)(now_ - t_real);            // ... and how long workgroups were busy with it
             st[91] = (first_ ? 0.0 : st[91]) + L[D_BWAIT]; st[92] = (first_ ? 0.0 : st[92]) + L[D_BWAIT + 1];
             for (int j_ = 0; j_ < 8; j_++) { o_[36 + j_] = (first_ ? 0.0 : o_[36 + j_]) + L[D_JWAIT + j_]; o_[48 + j_] = (first_ ? 0.0 : o_[48 + j_]) + L[D_JWAIT + 8 + j_]; }
+            for (int j_ = 0; j_ < 6; j_++) { double *r_ = o_ + ((j_ < 4) ? 44 + j_ : 52 + j_); *r_ = (first_ ? 0.0 : *r_) + (double)g_rt[j_]; }      // slots 44..47, 56, 57
             st[93] = (double)__builtin_amdgcn_s_getreg(63492);      // HW_ID of wave 0 (SIMD, CU, wave slot) | XCC_ID: where the robot ran
             st[95] = (double)__builtin_amdgcn_s_getreg(63508);
         }

@@ -6,6 +6,9 @@
       wait of each wave at every workgroup barrier; the evaluation stamped follows `pre` rollout ticks of bench.py's workload.
   python scripts/diag.py barrier [config=3] [ticks=200] [pre=1300]            needs LMH_DIAG=1
       share of the PRODUCTION rollout kernel's cycles that each wave of a robot spends inside workgroup barriers.
+  python scripts/diag.py ptimeline [config=3] [pre=1300] [instances=4096]   needs LMH_VARIANT=<a build with -DLMH_SUBSTAMPS -DLMH_DIAG_TL=stage>
+      the same timeline of the PRODUCTION rollout kernel: every mark both waves pass in the evaluation of Runge-Kutta stage `stage` of the
+      launch's last tick (the stamps go to the log buffer).
   python scripts/diag.py rounds [config=3] [ticks=4000] [chunk=100]
       QP round histogram (status[:, 1] = max rounds per launch) and flag counts along a rollout of bench.py's workload.
       The last line (per-robot launch cycles, max / mean) is the wave-slot occupancy proxy of the ticket scheduler: 1.0 = every robot
@@ -117,6 +120,9 @@ def barrier(argv):
     print("  wait per join of an evaluation, cycles (wave 0 | wave 1); the joins in order: X images, tree + references, QP fills, Cm | V, 15 x 15 solve | tiles, Y, recovery:")
     print("    w0: " + " ".join(f"{v:6.0f}" for v in o[:, 36:44].mean(axis=0) / ev))
     print("    w1: " + " ".join(f"{v:6.0f}" for v in o[:, 48:56].mean(axis=0) / ev))
+    rt = np.concatenate([o[:, 44:48].sum(axis=0), o[:, 56:58].sum(axis=0)])
+    if rt[4] > 0:
+        print(f"  cone solve per evaluation: all-free solve tried {rt[5]/rt[4]:.3f}, accepted {rt[0]/rt[4]:.3f};  rounds of the iteration: push-through {rt[1]/rt[4]:.3f}  thin {rt[2]/rt[4]:.3f}  general {rt[3]/rt[4]:.3f}")
     pc = np.percentile(tot / ev, [1, 10, 50, 90, 99])
     print("  cycles / evaluation percentiles 1/10/50/90/99: " + " ".join(f"{v:.0f}" for v in pc))
     for q in range(0, B, 512):
@@ -151,6 +157,54 @@ def rounds(argv):
         print(f"ticks {c*chunk:6d}..{(c+1)*chunk:6d}: max rounds per launch mean {s[:,1].mean():5.2f} max {s[:,1].max():3d}  flagged {int((fl != 0).sum()):5d} {kinds}  |F| mean {nF.mean():5.1f}  |v|max {float(state[:, 30:60].abs().max()):.2f}  base x {float(state[:, 0].min()):.2f}..{float(state[:, 0].max()):.2f}")
 
 
+PMARKS = {0: "evaluation starts", 46: "com_x: CoM done (w1)", 47: "com_x: E, p written", 48: "com_x: B written", 3: "com_x share done", 4: "  joined (X images)",
+          49: "NE: sweeps done", 50: "NE: body forces done", 51: "NE: backward sweep done", 52: "CRBA: levels done (w1)", 64: "NE done, Jacobian starts (w0)",
+          5: "tree share done", 66: "chain A starts (w1)", 67: "chain B starts (w0)", 68: "chain B done, prefill starts (w0)", 7: "references done", 8: "  joined (tree + references)",
+          10: "QP fills done", 11: "  joined (fills)", 12: "Cm | V tile done", 13: "  joined (Cm | V)", 14: "rows of Cm, V loaded (w0)", 15: "15 x 15 solve done (w0)",
+          60: "helper: RK4 stage starts", 69: "helper: RK4 stage done", 16: "  joined (solve | tiles)", 17: "Y tiles done (w1)", 63: "K_f^-1 prework starts (w1)",
+          19: "S tile done (w0)", 20: "S^-1 done (w0)", 22: "[W | h] done (w0)", 23: "set-up chain done (w0)", 18: "set-up done", 24: "cone starts (w0)", 30: "cone: entry",
+          32: "cone: 12 x 12 rows loaded", 33: "cone: 12 x 12 solved", 34: "cone: coefficients", 35: "cone: all-free verdict", 31: "cone: qv, qmax done", 80: "cone: thin solve starts",
+          81: "cone: thin solve done", 82: "cone: general solve starts", 83: "cone: general solve done", 84: "cone: 16-row solve starts", 85: "cone: 16-row solve done",
+          40: "  LDL': forward starts", 41: "  LDL': forward done", 42: "  LDL': factor parked", 43: "  LDL': backward done", 25: "cone done (w0)", 61: "look-ahead: references start (w1)",
+          62: "look-ahead: kinematics start (w1)", 44: "look-ahead: sin / cos stored (w1)", 45: "look-ahead: local transforms built (w1)", 70: "look-ahead done (w1)",
+          26: "recovery done (w0) | helper arrives (w1)", 27: "  joined (recovery)", 28: "outputs done", 71: "evaluation returns", 72: "integrator stage done"}
+
+
+def ptimeline(argv):
+    """per-wave timeline of ONE evaluation of the production rollout kernel (libraries built with -DLMH_SUBSTAMPS -DLMH_DIAG_TL=<stage>,
+    loaded through LMH_VARIANT): python scripts/diag.py ptimeline [config=3] [pre=1300] [instances=4096]"""
+    cfgno = int(argv[0]) if len(argv) > 0 else 3
+    pre = int(argv[1]) if len(argv) > 1 else 1300
+    B = int(argv[2]) if len(argv) > 2 else 4096
+    T = 8                                                          # 8 ticks x 36 doubles of log per robot >= the 256 the stamps take
+    args, ctl, state, host = setup(cfgno, B, pre + T + 2)
+    out, status = ctl.new_out(), ctl.new_status()
+    if pre:
+        ctl.rollout(state, pre, out, status)
+    log = torch.zeros((T, B, 36), dtype=torch.float64, device=ctl.device)
+    ctl.rollout(state, T, out, status, log)
+    torch.cuda.synchronize()
+    d = log.cpu().numpy().reshape(-1)[:256 * B].reshape(B, 256)
+    s = status.cpu().numpy()
+    ok = d[:, 0] > 0
+    w0, w1 = d[ok, 0:100], d[ok, 100:200]
+    t0 = w0[:, 0:1]
+    k = int(s[0, 0])
+    phase = host["phase"][k] if host["phase"] is not None else 0
+    print(f"config {cfgno}  {int(ok.sum())} robots  production rollout kernel, last tick of an {T}-tick launch after {pre} ticks, variant {os.environ.get('LMH_VARIANT', '')}  k {k}  support phase {int(phase)}")
+    print("(stamps cost ~70 cycles each on the wave that takes them; cycles since wave 0 entered the evaluation, mean over the robots; a wave that did not pass a mark: -)")
+    rows = []
+    for i, name in PMARKS.items():
+        a = [(w[:, i][w[:, i] > 0] - t0[w[:, i] > 0, 0]) for w in (w0, w1)]
+        if len(a[0]) == 0 and len(a[1]) == 0:
+            continue
+        m = [x.mean() if len(x) else float("nan") for x in a]
+        rows.append((np.nanmin(m), i, name, m, [len(x) for x in a]))
+    for _, i, name, m, n in sorted(rows):
+        f = lambda v, c: ("%10.0f" % v + ("" if c == int(ok.sum()) else " (%d)" % c)) if c else "         -"
+        print("%-46s [%2d] %-18s %-18s" % (name, i, f(m[0], n[0]), f(m[1], n[1])))
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "timeline"
-    {"timeline": timeline, "barrier": barrier, "rounds": rounds}[cmd](sys.argv[2:])
+    {"timeline": timeline, "ptimeline": ptimeline, "barrier": barrier, "rounds": rounds}[cmd](sys.argv[2:])
