@@ -2905,9 +2905,9 @@ __device__ __forceinline__ int qp_setup15(double *L, LmhCParams &P, int wid, dou
     {   // lane = (row parity hi, column c); everything derived from the lane once, a pass is a load, one or two multiplications and the stores
         const int c = lane & 31, hi = lane >> 5, cs = (c < 30) ? c : 0;
         const double iDc = (c < 3) ? idp : (c < 6) ? ida : idj, dm = (c < 30) ? iDc : 0.0;          // 1 / D_c, 0 on the padding columns
-        // NW = 2: all of these fills are wave 0's -- the helper is the later one at this join (it forms q meanwhile, and comes out of the longer
-        // reference chain), wave 0 used to wait ~0.7k cycles here (profiles/r04_barrier_share.txt)
-        if (wid == 0) {                                            // rows 12..15 of U, U D^-1
+        // NW = 2: the helper forms q (below) and the momentum rows of U, wave 0 AGpqp, bp'' and the weights: with everything but q on wave 0 the
+        // helper waited ~0.7k cycles at this join, with the bp'' rows split as well wave 0 did (profiles/r04_barrier_share*.txt)
+        if (wid == NW - 1) {                                       // rows 12..15 of U, U D^-1
             const double um = (c < 30) ? 1.0 : 0.0;
             const double *ag = L + (P_AG + 90 + 30 * hi + cs);     // linear-momentum rows 3..5 of AG -> operand rows 12..14; row 15 is zero
             double *o = L + (Q_U + 34 * (12 + hi) + c);
