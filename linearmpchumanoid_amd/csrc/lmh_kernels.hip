@@ -2773,7 +2773,9 @@ __device__ __forceinline__ int cone_qp(double *L, LmhCParams &P, unsigned forced
                 if (solve_free_set_thin<8>(L, F, P.eps_coeff, &zj, &lj)) flags |= LMH_FLAG_NOT_SPD;
                 w_thin = true;
                 WSTAMP(81);
-#ifndef LMH_NO_THIN16
+#ifdef LMH_THIN16                                                   // experiment switch: measured 17.0k cycles against the general route's 16.8k for |F| = 16 (a
+            // 16-pivot dependent chain does not get cheaper by staying in registers), so the shipped kernel does not carry it; what removed that
+            // solve from the walking workload is the edge-contact push-through (cone_pushthrough)
             } else if (__builtin_amdgcn_readfirstlane(__popc(F)) <= 16) {      // up to 16 rows: the same solve, one DPP row full
                 WSTAMP(84);
                 RT_COUNT(2);

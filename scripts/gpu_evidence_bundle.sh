@@ -25,12 +25,18 @@ if [ $PART = diag ] || [ $PART = all ]; then
   timeout -k 10 300 python scripts/diag.py barrier 3 1000 1000 > gpurun_out/r04_barrier_share.txt 2>&1
   timeout -k 10 300 python scripts/diag.py barrier 3 200 1300 >> gpurun_out/r04_barrier_share.txt 2>&1
   timeout -k 10 300 python scripts/diag.py barrier 3 200 1100 >> gpurun_out/r04_barrier_share.txt 2>&1
+  timeout -k 10 300 python scripts/diag.py barrier 3 200 1500 >> gpurun_out/r04_barrier_share.txt 2>&1
   timeout -k 10 300 python scripts/diag.py barrier 2 200 600 >> gpurun_out/r04_barrier_share.txt 2>&1
   timeout -k 10 300 python scripts/diag.py barrier 5 200 600 >> gpurun_out/r04_barrier_share.txt 2>&1
   LMH_DIAG_NW2=1 timeout -k 10 200 python scripts/diag.py timeline 3 1120 > gpurun_out/tl_ds.txt 2>&1
   LMH_DIAG_NW2=1 timeout -k 10 200 python scripts/diag.py timeline 3 1300 > gpurun_out/tl_ss.txt 2>&1
   timeout -k 10 200 python scripts/gpu_phase_stamps.py 1024 1 40 > gpurun_out/r04_phase_stamps.txt 2>&1
   unset LMH_DIAG
+  # production-kernel timeline (variant tl1 = -DLMH_SUBSTAMPS -DLMH_DIAG_TL=1, built beside the diagnostic library: see profiles/README.md) and the free sets along the gait
+  : > gpurun_out/r04_prod_timeline.txt
+  for t in 1120 1350 1550; do LMH_VARIANT=tl1 timeout -k 10 200 python scripts/diag.py ptimeline 3 $t >> gpurun_out/r04_prod_timeline.txt 2>&1; echo >> gpurun_out/r04_prod_timeline.txt; done
+  LMH_VARIANT=tl1 timeout -k 10 200 python scripts/diag.py ptimeline 2 600 1024 >> gpurun_out/r04_prod_timeline.txt 2>&1
+  timeout -k 10 300 python scripts/route_probe.py 3 1024 > gpurun_out/r04_route_probe.txt 2>&1
   timeout -k 10 300 python scripts/diag.py rounds 3 4000 400 > gpurun_out/r04_qp_rounds.txt 2>&1
   timeout -k 10 300 python scripts/diag.py rounds 2 2000 200 >> gpurun_out/r04_qp_rounds.txt 2>&1
   timeout -k 10 600 python scripts/precision_sweep.py 1024 600 gpurun_out/r04_precision_sweep.json > gpurun_out/sweep.log 2>&1
