@@ -23,7 +23,9 @@ def needs_build():
 #   poison : every robot starts from an LDS image full of NaNs (tests/test_gpu_round3.py: no result depends on LDS nobody wrote)
 #   qfault : work-queue fault injection -- the pushes of every seventh robot are lost and the waits give up after 64 polls
 #            (tests/test_gpu_round4.py: an incomplete rollout is loud and leaves a clean launch slot)
-CHECKER_VARIANTS = {"poison": ["-DLMH_POISON"], "qfault": ["-DLMH_SPIN_LIMIT=64", "-DLMH_TEST_LOSE_PUSH=7"]}
+#   noedge:  -DLMH_NO_EDGE -- the edge-contact form of the push-through solve is off: a foot pressing on one side of its sole goes the
+#            register / general route (tests/test_gpu_round4.py compares the two routes through a touch-down)
+CHECKER_VARIANTS = {"poison": ["-DLMH_POISON"], "qfault": ["-DLMH_SPIN_LIMIT=64", "-DLMH_TEST_LOSE_PUSH=7"], "noedge": ["-DLMH_NO_EDGE"]}
 
 
 def _hipcc_cmd(so, extra):

@@ -684,6 +684,42 @@ __device__ __forceinline__ void gj16_step(double (&a)[N], double (&b)[M], unsign
         gj16_step<J + 1, N, M, GUARD>(a, b, live, l16, rowon, dmin, bad, myinv);
     }
 }
+// (-DLMH_GJ_PIPE only; measured and not shipped: wave 0's chain gets shorter, but the extra wait states it takes are issue slots the SIMD's
+// other wave -- another robot's helper -- no longer gets, and the kernel's throughput follows the SIMD's total instruction count:
+// 16.36 -> 16.00 M ticks/s on config 3.)
+// The guard-free form, software-pipelined: the reciprocal of pivot J + 1 -- broadcast, v_rcp_f64, one Newton step: ~100 cycles of dependent
+// latency, the longest link of a pivot's chain -- needs column J + 1 of pivot J's update only, so that column is updated by its own asm
+// statement, the reciprocal chain starts, and the block of the other columns and the right-hand sides issues inside its latency
+// (with all of a pivot's updates in one asm statement the chain could only start behind the block: a 15 x 15 solve with 7 right-hand
+// sides spent 21..7 issue slots per pivot that way).  `invd`: 1 / d_J handed over by pivot J - 1 (`have`: it is; wave-uniform).
+template <int J, int N, int M>
+__device__ __forceinline__ void gj16_pipe(double (&a)[N], double (&b)[M], unsigned live, int l16, double &myinv, double invd, bool have)
+{
+    if constexpr (J < N) {
+        bool have_next = false;
+        double invn = 0.0;
+        if ((live >> J) & 1u) {                                   // wave-uniform
+            if (!have) invd = fast_rcp1(bcast16<J>(a[J]));         // (first live pivot, or the one before was not live)
+            const bool piv = l16 == J;
+            const double nf = piv ? 0.0 : -(a[J] * invd);
+            myinv = piv ? invd : myinv;
+            if constexpr (J + 1 < N) {
+                // column J + 1, then straight away the broadcast of the next pivot and its v_rcp_f64 -- inside ONE asm statement: the compiler's
+                // scheduler sees no latency in an asm and had moved a separately written reciprocal behind the block of the other columns
+                double dn, rn;
+                asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                             "v_mov_b64_dpp %1, %0 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_rcp_f64_e32 %2, %1"
+                             : "+v"(a[J + 1]), "=&v"(dn), "=&v"(rn) : "v"(nf), "n"(J), "n"(J + 1));
+                dpp_fmac_self<J + 2, N - 2 - J, J>(a, nf);
+                dpp_fmac_self<0, M, J>(b, nf);
+                asm volatile("" : "+v"(dn), "+v"(rn));             // the Newton step stays behind the blocks
+                invn = fma(fma(-dn, rn, 1.0), rn, rn);
+                have_next = ((live >> (J + 1)) & 1u) != 0u;
+            } else dpp_fmac_self<0, M, J>(b, nf);
+        }
+        gj16_pipe<J + 1, N, M>(a, b, live, l16, myinv, invn, have_next);
+    }
+}
 // Lane l holds row l & 15 of the system (rows >= N: any finite copy, e.g. row 0 -- they are eliminated like every other row and never read):
 // all four 16-lane DPP rows then run the same elimination.  On exit b[r] of lane i < N holds x_i.  Returns non-zero (wave-uniform) if a
 // pivot was not positive (d_i > 0 <=> 0 < 1 / d_i < inf on the lane that kept it; the caller flags LMH_FLAG_NOT_SPD, and the non-finite
@@ -695,7 +731,11 @@ __device__ __forceinline__ int gj_solve_regs(double (&a)[N], double (&b)[M], uns
     const int l16 = LANE & 15;
     int bad = 0;
     double myinv = 0.0;
+#ifdef LMH_GJ_PIPE                                                  // experiment switch: the software-pipelined pivots (gj16_pipe): measured -2.2 %
+    gj16_pipe<0, N, M>(a, b, live, l16, myinv, 0.0, false);
+#else
     gj16_step<0, N, M, false>(a, b, live, l16, true, 0.0, bad, myinv);
+#endif
 #pragma unroll
     for (int r = 0; r < M; r++) b[r] *= myinv;
     const bool pivot_lane = ((live >> l16) & 1u) != 0u;            // (bits >= N of `live` are clear)
@@ -2270,6 +2310,9 @@ __device__ __forceinline__ int solve_free_set_thin(double *L, unsigned F_in, dou
 // d: 0 = tau_x bound, 1 = tau_y bound, -1 = none (wave-uniform, from the foot's 16-bit free mask)
 __device__ __forceinline__ int edge_bound_row(unsigned Ff)
 {
+#ifdef LMH_NO_EDGE                                                  // checker build `noedge`: such sets go the register / general route as before round 4
+    return -1;
+#endif
     if (Ff == 0u) return -1;
     if ((Ff & ~0x0F0Fu) == 0u || (Ff & ~0xF0F0u) == 0u) return 0;
     if ((Ff & ~0x00FFu) == 0u || (Ff & ~0xFF00u) == 0u) return 1;
@@ -2363,7 +2406,7 @@ __device__ __forceinline__ int cone_pushthrough(double *L, LmhCParams &P, unsign
         }
         const double hv = L[P_H12 + lr] + kz * L[P_H12 + 6 * fi + ((dd > 0) ? dd : 0)];
         b[0] = rowpin ? 0.0 : hv;
-        const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);
+        const unsigned live = (useR ? 0x03Fu : 0u) | (useL ? 0xFC0u : 0u);      // (a pinned row stays a pivot: skipping it measured neutral)
         if (gj_solve_regs<12, 1>(a, b, live)) *flags |= LMH_FLAG_NOT_SPD;
         // w = E w~: the bound torque is kappa f_z (lanes 5 / 11 of the lane's own 16-lane row hold f_z)
         const double fzR = bcast16<5>(b[0]), fzL = bcast16<11>(b[0]);

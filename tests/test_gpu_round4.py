@@ -182,3 +182,75 @@ def test_bench_eval_mode_reports_both_lines():
     assert b1["cpu_oracle_single_core"]["cores"] == 1 and b1["cpu_oracle_single_core"]["ms_per_tick"] > 0.0
     app = b1["offline_stand_app"]
     assert app["returncode"] == 0 and abs(app["last_com_x"] - (-1.34198e-4)) < 1e-8
+
+
+# ------------------------------------------------------------------------------- edge-contact push-through (cone_pushthrough, round 4)
+_EDGE_PROBE = r"""
+import json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+from linearmpchumanoid_amd.controller import BatchedController, default_config
+ik = json.load(open("tests/golden/ik_posture.json"))
+B, N, NT, CH = 8, 32, 900, 50
+ctl = BatchedController(B, default_config(dt=1e-3, time_horizon=N * 1e-2 + 1e-9, z_com=ik["z_com"], mpc_dt=1e-2, warm_start=1))
+ctl.gen_walk(2.0, num_steps=3, time_per_step=0.5, ds_time=0.2, step_height=0.02, settle_time=0.1)
+ctl.set_xscale(np.linspace(0.02, 0.05, B))
+st = ctl.new_state(np.array(ik["q"]), np.zeros(30), t=0.0)
+logs, masks, flags = [], [], 0
+for c in range(NT // CH):
+    out, status, log = ctl.rollout(st, CH, log=True)
+    torch.cuda.synchronize()
+    s = status.cpu().numpy()
+    logs.append(log.cpu().numpy()); flags |= int(np.bitwise_or.reduce(s[:, 2]))
+    masks.append([int((~int(x)) & 0xFFFFFFFF) for x in s[:, 3]])
+path = sys.argv[1]
+np.save(path, np.concatenate(logs, axis=0))
+print(json.dumps({"flags": flags, "masks": masks}))
+"""
+
+
+def test_edge_contact_pushthrough_against_the_other_routes_and_the_oracle(tmp_path):
+    """A foot that presses on one side of its sole (free coefficients on two vertices of one edge: K_f has rank 5) is solved by the
+    push-through system in its five free wrench coordinates (cone_pushthrough) -- the set of every double support right
+    after a touch-down of the walking gait.  The checker build `noedge` (-DLMH_NO_EDGE) sends the same sets down the register / general
+    route: the two libraries must meet such sets (the free-set masks say so), differ in rounding only, and the shipped one must agree with
+    the C oracle through the touch-downs like everywhere else."""
+    from linearmpchumanoid_amd import build as hipbuild
+    from oracle.pyoracle import Oracle
+    hipbuild.build_variant("noedge")
+    res, logs = {}, {}
+    for variant in ("", "noedge"):
+        path = str(tmp_path / f"edge_{variant or 'shipped'}.npy")
+        code = _EDGE_PROBE.replace("sys.argv[1]", repr(path))
+        res[variant] = _run_probe(code, variant)
+        logs[variant] = np.load(path)
+        assert res[variant]["flags"] == 0
+    # the gait met edge sets: some foot's free mask lies on one side of the sole (vertices 0, 2 | 1, 3 | 0, 1 | 2, 3) with at least six members
+    def edge_foot(m):
+        return m != 0 and bin(m).count("1") >= 6 and any((m & ~side) == 0 for side in (0x0F0F, 0xF0F0, 0x00FF, 0xFF00))
+    n_edge = sum(1 for launch in res[""]["masks"] for f in launch if edge_foot(f & 0xFFFF) or edge_foot(f >> 16))
+    assert n_edge >= 8, n_edge
+    a, b = logs[""], logs["noedge"]
+    assert a.shape == b.shape == (900, 8, 36)
+    assert not np.array_equal(a, b)                                # the routes differ in rounding, so the edge form really ran
+    worst = 0.0
+    for tk in range(a.shape[0]):
+        for i in range(a.shape[1]):
+            worst = max(worst, vec_err(a[tk, i, :24], b[tk, i, :24]), np.abs(a[tk, i, 24:] - b[tk, i, 24:]).max() / WEIGHT)
+    assert worst < 1e-7, worst
+    # the shipped library against the oracle on two robots, every third tick (the touch-downs of this gait fall at ticks 300 and 800)
+    ik = json.load(open(os.path.join(ROOT, "tests", "golden", "ik_posture.json")))
+    from linearmpchumanoid_amd.controller import BatchedController, default_config
+    ctl = BatchedController(8, default_config(dt=DT, time_horizon=32 * 1e-2 + 1e-9, z_com=ik["z_com"], mpc_dt=1e-2, warm_start=1))
+    ctl.gen_walk(2.0, num_steps=3, time_per_step=0.5, ds_time=0.2, step_height=0.02, settle_time=0.1)
+    plan = ctl.get_refs()
+    xs = np.linspace(0.02, 0.05, 8)
+    for i in (0, 7):
+        o = Oracle(sim_time=2.0, dt=1e-2, horizon_time=32 * 1e-2 + 1e-9, do_ik=True)
+        o.set_refs(plan["zmp_x"], plan["zmp_y"], plan["phase"])
+        o.set_segments(plan["segs"], plan["seg_of_sample"], xscale=float(xs[i]))
+        r = o.rollout(np.concatenate([np.array(ik["q"]), np.zeros(30)]), 0.0, 900, dt=DT, log=True)
+        for tk in range(0, 900, 3):
+            ref = r["log"][tk]
+            assert close(a[tk, i, :24], ref[:24], 1e-6), (i, tk, vec_err(a[tk, i, :24], ref[:24]))
+            assert close(a[tk, i, 24:], ref[24:], 1e-6, scale=WEIGHT), (i, tk, vec_err(a[tk, i, 24:], ref[24:]))
