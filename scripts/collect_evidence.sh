@@ -3,7 +3,7 @@
 # Every piece is optional: what a partial bundle did not produce is skipped.
 cd "$(dirname "$0")/.."
 for t in r04_c3 r04_c2; do [ -d gpurun_out/prof_$t ] && python scripts/summarise_profile.py $t > /dev/null; done
-for f in bench_r04_c3 bench_r04_c2 bench_r04_c5 bench_r04_c3_coupled bench_r04_c3_hostio bench_r04_2rank_gloo bench_r04_c2_push1 bench_r04_eval; do [ -s gpurun_out/$f.json ] && cp gpurun_out/$f.json profiles/$f.json; done
+for f in bench_r04_c3 bench_r04_c2 bench_r04_c5 bench_r04_c3_coupled bench_r04_c3_hostio bench_r04_2rank_gloo bench_r04_c2_push1 bench_r04_eval bench_r04_c3_steps20; do [ -s gpurun_out/$f.json ] && cp gpurun_out/$f.json profiles/$f.json; done
 [ -s gpurun_out/r04_barrier_share.txt ] && grep -v amdgpu gpurun_out/r04_barrier_share.txt > profiles/r04_barrier_share.txt
 [ -s gpurun_out/r04_prod_timeline.txt ] && grep -v amdgpu gpurun_out/r04_prod_timeline.txt > profiles/r04_prod_timeline.txt
 [ -s gpurun_out/r04_route_probe.txt ] && grep -v amdgpu gpurun_out/r04_route_probe.txt > profiles/r04_route_probe.txt
