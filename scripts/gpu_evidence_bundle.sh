@@ -12,6 +12,7 @@ fi
 if [ $PART = bench ] || [ $PART = all ]; then
   timeout -k 10 600 python bench.py > gpurun_out/bench_r04_c3.json 2> gpurun_out/bench_r04_c3.err
   timeout -k 10 600 python bench.py --config 2 > gpurun_out/bench_r04_c2.json 2> gpurun_out/bench_r04_c2.err
+  timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_r04_c3_steps20.json 2> gpurun_out/bench_r04_c3_steps20.err   # the driver's flags
   timeout -k 10 600 python bench.py --config 5 --no-cpu-baseline > gpurun_out/bench_r04_c5.json 2> gpurun_out/bench_r04_c5.err
   timeout -k 10 600 python bench.py --coupled --no-cpu-baseline > gpurun_out/bench_r04_c3_coupled.json 2> gpurun_out/bench_r04_c3_coupled.err
   timeout -k 10 600 python bench.py --host-io --no-cpu-baseline > gpurun_out/bench_r04_c3_hostio.json 2> gpurun_out/bench_r04_c3_hostio.err
