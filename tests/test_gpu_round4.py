@@ -254,3 +254,73 @@ def test_edge_contact_pushthrough_against_the_other_routes_and_the_oracle(tmp_pa
             ref = r["log"][tk]
             assert close(a[tk, i, :24], ref[:24], 1e-6), (i, tk, vec_err(a[tk, i, :24], ref[:24]))
             assert close(a[tk, i, 24:], ref[24:], 1e-6, scale=WEIGHT), (i, tk, vec_err(a[tk, i, 24:], ref[24:]))
+
+
+_EDGE_SIDES_PROBE = r"""
+import json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+from linearmpchumanoid_amd.controller import BatchedController, default_config
+ik = json.load(open("tests/golden/ik_posture.json"))
+v = np.load(sys.argv[2])
+B = v.shape[0]
+ctl = BatchedController(B, default_config(dt=1e-3, time_horizon=0.32 + 1e-9, z_com=ik["z_com"], mpc_dt=1e-2, warm_start=0))
+ctl.set_refs_stance(1.0, 2)
+st = ctl.new_state(np.array(ik["q"]), v, t=0.0)
+out, status = ctl.stand_step(st)
+torch.cuda.synchronize()
+s = status.cpu().numpy()
+np.save(sys.argv[1], out.cpu().numpy())
+print(json.dumps({"flags": s[:, 2].tolist(), "rounds": s[:, 1].tolist(), "masks": [int((~int(x)) & 0xFFFFFFFF) for x in s[:, 3]]}))
+"""
+
+
+def _push_velocities():
+    """base velocity pushes of a standing robot in eight directions: the contact solve ends on the heel side, on either lateral side, on
+    corners -- and, pushed hard backwards, on the toe side"""
+    dirs = [(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (1, -1), (-1, 1), (-1, -1)]
+    mags = [0.05, 0.1, 0.15, 0.2, 0.25, 0.3, 0.4, 0.5]
+    rows = [(d[0] * m, d[1] * m * 0.5) for d in dirs for m in mags] + [(-m, 0.0) for m in (0.6, 0.7, 0.8, 0.9, 1.0, 1.2, 1.5, 2.0)]
+    v = np.zeros((len(rows), 30))
+    v[:, 0] = [r[0] for r in rows]; v[:, 1] = [r[1] for r in rows]
+    return v
+
+
+def test_edge_contact_on_every_side_of_the_sole_against_the_general_route_and_the_oracle(tmp_path):
+    """A standing robot pushed in eight directions (cold start, the iteration run to its end): the accepted free sets sit on the heel side
+    (tau_y = -p_x f_z bound), on either lateral side (tau_x = p_y f_z bound; the walking gait only ever meets one of them), on corners and on
+    mixed patterns.  The shipped library (edge-contact push-through) against the checker build `noedge` (register / general route on the same
+    sets): same rounds, same final sets, results equal to rounding; the robots that end on an edge also against the C oracle."""
+    from linearmpchumanoid_amd import build as hipbuild
+    from oracle.pyoracle import Oracle
+    hipbuild.build_variant("noedge")
+    v = _push_velocities()
+    vpath = str(tmp_path / "v.npy")
+    np.save(vpath, v)
+    outs, res = {}, {}
+    for variant in ("", "noedge"):
+        path = str(tmp_path / f"sides_{variant or 'shipped'}.npy")
+        res[variant] = _run_probe(_EDGE_SIDES_PROBE.replace("sys.argv[1]", repr(path)).replace("sys.argv[2]", repr(vpath)), variant)
+        outs[variant] = np.load(path)
+    a, b = outs[""], outs["noedge"]
+    assert all(f == 0 for f in res[""]["flags"]) and all(f == 0 for f in res["noedge"]["flags"])
+    assert res[""]["masks"] == res["noedge"]["masks"] and res[""]["rounds"] == res["noedge"]["rounds"]
+    sides = {0x0F0F: "y+", 0xF0F0: "y-", 0x00FF: "x+", 0xFF00: "x-"}
+    def side_of(m):
+        return next((n for sd, n in sides.items() if m != 0 and bin(m).count("1") >= 6 and (m & ~sd) == 0), None)
+    seen, edge_robots = set(), []
+    for i, f in enumerate(res[""]["masks"]):
+        sr, sl = side_of(f & 0xFFFF), side_of(f >> 16)
+        if sr or sl:
+            seen.update(x for x in (sr, sl) if x); edge_robots.append(i)
+    assert {"y+", "y-", "x-"} <= seen, seen                        # both lateral sides and the heel side (tau_y bound) are met
+    worst = 0.0
+    for i in range(a.shape[0]):
+        worst = max(worst, vec_err(a[i, :24], b[i, :24]), np.abs(a[i, 24:36] - b[i, 24:36]).max() / WEIGHT, vec_err(a[i, 36:66], b[i, 36:66]))
+    assert worst < 1e-7, worst
+    assert any(not np.array_equal(a[i], b[i]) for i in edge_robots)
+    ik = json.load(open(os.path.join(ROOT, "tests", "golden", "ik_posture.json")))
+    o = Oracle(sim_time=1.0, dt=1e-2, horizon_time=0.32 + 1e-9, do_ik=True)
+    for i in edge_robots[::2]:
+        e = o.eval(np.array(ik["q"]), v[i], 0.0)
+        assert close(a[i, :24], e["tau"]) and close(a[i, 24:36], e["f"], scale=WEIGHT) and close(a[i, 36:66], e["qpp"]), (i, hex(res[""]["masks"][i]))
